@@ -1,0 +1,7 @@
+"""sttfe -- MI355X-native audio front-end (log-mel / Kaldi fbank / resample / SpecAugment).
+
+Host side of the drop-in for the feature-extraction path of Alexey511/speech_to_text
+(reference ``src/processors.py`` / ``src/data.py``).  All arithmetic runs in hand-written HIP
+kernels behind the C-ABI library ``libsttfe.so`` (``include/sttfe.h``); there is no CPU fallback.
+"""
+__version__ = "0.1.0"
