@@ -1,0 +1,79 @@
+/*
+ * sttfe.h -- C ABI of libsttfe.so, the MI355X (gfx950) audio front-end.
+ *
+ * Drop-in boundary for the feature-extraction path of Alexey511/speech_to_text.  The reference is
+ * pure Python, so there is no existing FFI to match; each entry point below replaces the Python
+ * call cited next to it (paths relative to the reference repo; "HF:" = the transformers package
+ * the reference pins in requirements.txt:11).  A maintainer binds these with ctypes -- see
+ * INTEGRATION.md for the stub.
+ *
+ * Conventions
+ *   - every function returns 0 (STTFE_OK) or a negative STTFE_E_* code; sttfe_strerror() names it;
+ *   - "device" pointers are HIP device memory owned by the caller (e.g. torch tensors); the
+ *     library never allocates, frees or synchronises; all work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream);
+ *   - "host" pointers are ordinary host memory;
+ *   - tables: constant data a kernel needs (window, twiddles, banded mel weights) is produced by a
+ *     *_tables_build() call into a HOST buffer; the caller copies that blob to the device once and
+ *     passes the device copy to the kernels;
+ *   - PCM is float32, one clip after another in one buffer; clip b starts at pcm[offsets[b]] and
+ *     has lengths[b] valid samples (offsets / lengths are DEVICE arrays: no host sync needed when
+ *     an earlier kernel produced them).
+ */
+#ifndef STTFE_H
+#define STTFE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STTFE_OK 0
+#define STTFE_E_INVALID_ARG (-1)   /* NULL pointer, negative size, unsupported n_mels ... */
+#define STTFE_E_WORKSPACE (-2)     /* workspace too small */
+#define STTFE_E_TABLES (-3)        /* tables blob does not match the call */
+#define STTFE_E_LAUNCH (-4)        /* HIP reported a launch error */
+#define STTFE_E_UNSUPPORTED (-5)   /* sampling-rate ratio / size outside what the kernels handle */
+
+#define STTFE_AXIS_FREQ 0
+#define STTFE_AXIS_TIME 1
+
+int sttfe_version(void);
+const char* sttfe_strerror(int code);
+
+/* ---------------------------------------------------------------- Whisper log-mel (row W) ----
+ * Replaces processor.feature_extractor(audio_np, sampling_rate=16000, return_tensors="pt")
+ * for WhisperProcessor: src/data.py:338-343, inference.py:148-152, and the batched
+ * TorchWhisperFeatureExtractor.__call__ of src/processors.py:148-246.  Arithmetic =
+ * HF:models/whisper/feature_extraction_whisper.py:135-168,300-307.
+ */
+
+/* Size of / fill the host tables blob for an n_mels-bin extractor (n_mels in [1,128]). */
+int sttfe_whisper_tables_bytes(int n_mels, size_t* bytes);
+int sttfe_whisper_tables_build(int n_mels, void* host_blob, size_t bytes);
+/* The dense (n_mels x 201) float32 mel bank the tables were derived from (for inspection/tests). */
+int sttfe_whisper_mel_bank(int n_mels, float* host_dense);
+
+/* Bytes of device workspace needed for a batch (per-clip max keys). */
+int sttfe_whisper_workspace_bytes(int batch, size_t* bytes);
+
+/*
+ * pcm/offsets/lengths : device; clips at 16 kHz; samples past lengths[b] (up to 480000) count as 0,
+ *                       samples past 480000 are ignored (HF pad/truncate to 30 s).
+ * out                 : device float32 [batch][n_mels][n_frames], n_frames = 3000 for HF parity.
+ * mask_tbl            : device int32 [batch][n_masks][3] = {axis, start, end} or NULL; elements
+ *                       with start <= index < end along the axis are set to 0.0 AFTER the
+ *                       log/clamp/scale (SpecAugment, src/data.py:185-194); rows with end<=start
+ *                       are no-ops.
+ */
+int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, const int32_t* lengths,
+                         int batch, int n_mels, int n_frames, const void* dev_tables,
+                         float* out, const int32_t* mask_tbl, int n_masks,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STTFE_H */

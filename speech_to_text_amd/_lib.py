@@ -1,0 +1,68 @@
+"""ctypes binding of libsttfe.so (include/sttfe.h).  No fallback: a missing library is an error."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsttfe.so")
+
+_lib = None
+
+
+class SttfeError(RuntimeError):
+    pass
+
+
+def _declare(lib):
+    p = c_void_p
+    lib.sttfe_version.restype = c_int
+    lib.sttfe_strerror.restype = c_char_p
+    lib.sttfe_strerror.argtypes = [c_int]
+    sigs = {
+        "sttfe_whisper_tables_bytes": [c_int, POINTER(c_size_t)],
+        "sttfe_whisper_tables_build": [c_int, p, c_size_t],
+        "sttfe_whisper_mel_bank": [c_int, p],
+        "sttfe_whisper_workspace_bytes": [c_int, POINTER(c_size_t)],
+        "sttfe_whisper_logmel": [p, p, p, c_int, c_int, c_int, p, p, p, c_int, p, c_size_t, p],
+        "sttfe_set_whisper_chunk": [c_int],
+        "sttfe_kaldi_tables_bytes": [c_int, POINTER(c_size_t)],
+        "sttfe_kaldi_tables_build": [c_int, p, c_size_t],
+        "sttfe_kaldi_mel_bank": [c_int, p],
+        "sttfe_kaldi_workspace_bytes": [c_int, c_int, POINTER(c_size_t)],
+        "sttfe_kaldi_fbank_cmvn": [p, p, p, c_int, c_int, c_int, c_int, p, p, p, c_int, p, c_int, p, c_size_t, p],
+        "sttfe_resample_taps": [c_int, c_int, p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)],
+        "sttfe_resample_peak": [p, p, p, c_int, c_int, c_int, p, c_int, p, p, p, p, p],
+        "sttfe_normalize_trim": [p, p, p, c_int, c_int, c_int, c_float, p, p, p, p],
+    }
+    for name, args in sigs.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            continue          # declared in the header but not built yet -> tests/test_boundary_cpu.py fails
+        fn.restype = c_int
+        fn.argtypes = args
+
+
+def lib():
+    """The loaded library (loads on first use).  Raises SttfeError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SttfeError(
+                f"{LIB_PATH} not found: build it with `make -C speech_to_text_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def check(code: int, what: str = "sttfe"):
+    if code != 0:
+        msg = lib().sttfe_strerror(code)
+        raise SttfeError(f"{what} failed: {msg.decode() if msg else code} ({code})")
+
+
+def ptr(t):
+    """Device/host address of a torch tensor (or None)."""
+    return None if t is None else c_void_p(t.data_ptr())

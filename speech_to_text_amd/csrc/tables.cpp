@@ -1,0 +1,176 @@
+// Host-side builders for the constant tables (mel banks, windows, twiddles, MFMA mel plans).
+// Pure C++ double-precision math; no GPU calls.  The filter-bank definitions follow the formulas
+// of the Hugging Face extractors the reference calls (HF:audio_utils.py:448-517,541-560,638-729);
+// tests/test_tables_cpu.py checks them against the NumPy oracle.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/sttfe.h"
+#include "tables.h"
+
+namespace sttfe {
+
+static double hz_to_mel_slaney(double f) {
+    if (f >= 1000.0) return 15.0 + std::log(f / 1000.0) * (27.0 / std::log(6.4));
+    return 3.0 * f / 200.0;
+}
+static double mel_to_hz_slaney(double m) {
+    if (m >= 15.0) return 1000.0 * std::exp((std::log(6.4) / 27.0) * (m - 15.0));
+    return 200.0 * m / 3.0;
+}
+static double hz_to_mel_kaldi(double f) { return 1127.0 * std::log(1.0 + f / 700.0); }
+
+// Triangular bank (n_mels x n_bins), given the coordinates of the FFT bins and of the n_mels + 2
+// filter edge points in the same unit (Hz for Whisper, mel for Kaldi).
+static void triangular_bank(const std::vector<double>& bin_pos, const std::vector<double>& pts,
+                            int n_mels, std::vector<double>& w) {
+    const int n_bins = (int)bin_pos.size();
+    w.assign((size_t)n_mels * n_bins, 0.0);
+    for (int m = 0; m < n_mels; ++m) {
+        const double lo = pts[m], ce = pts[m + 1], hi = pts[m + 2];
+        for (int k = 0; k < n_bins; ++k) {
+            const double down = -(lo - bin_pos[k]) / (ce - lo);   // rising edge
+            const double up = (hi - bin_pos[k]) / (hi - ce);      // falling edge
+            w[(size_t)m * n_bins + k] = std::max(0.0, std::min(down, up));
+        }
+    }
+}
+
+void whisper_mel_bank(int n_mels, std::vector<float>& dense) {
+    const int n_bins = 201;
+    std::vector<double> pts(n_mels + 2), bins(n_bins), w;
+    const double m0 = hz_to_mel_slaney(0.0), m1 = hz_to_mel_slaney(8000.0);
+    for (int i = 0; i < n_mels + 2; ++i)
+        pts[i] = mel_to_hz_slaney(m0 + (m1 - m0) * (double)i / (double)(n_mels + 1));
+    for (int k = 0; k < n_bins; ++k) bins[k] = 8000.0 * (double)k / (double)(n_bins - 1);
+    triangular_bank(bins, pts, n_mels, w);
+    dense.resize(w.size());
+    for (int m = 0; m < n_mels; ++m) {
+        const double enorm = 2.0 / (pts[m + 2] - pts[m]);          // slaney area normalisation
+        for (int k = 0; k < n_bins; ++k)
+            dense[(size_t)m * n_bins + k] = (float)(w[(size_t)m * n_bins + k] * enorm);
+    }
+}
+
+void kaldi_mel_bank(int n_mels, std::vector<float>& dense) {
+    const int n_bins = 257;
+    std::vector<double> pts(n_mels + 2), bins(n_bins), w;
+    const double m0 = hz_to_mel_kaldi(20.0), m1 = hz_to_mel_kaldi(8000.0);
+    for (int i = 0; i < n_mels + 2; ++i) pts[i] = m0 + (m1 - m0) * (double)i / (double)(n_mels + 1);
+    const double bin_width = 16000.0 / ((n_bins - 1) * 2);
+    for (int k = 0; k < n_bins; ++k) bins[k] = hz_to_mel_kaldi(bin_width * k);
+    triangular_bank(bins, pts, n_mels, w);
+    dense.resize(w.size());
+    for (size_t i = 0; i < w.size(); ++i) dense[i] = (float)w[i];
+}
+
+// Build the banded MFMA plan + A fragments from a dense (n_mels x n_bins) bank times `scale`.
+void build_mel_plan(const std::vector<float>& dense, int n_mels, int n_bins, float scale,
+                    MelPlan& plan, std::vector<float>& afrag) {
+    std::memset(&plan, 0, sizeof(plan));
+    plan.n_mels = n_mels;
+    plan.n_bins = n_bins;
+    plan.n_mtiles = (n_mels + 15) / 16;
+    afrag.clear();
+    for (int mt = 0; mt < plan.n_mtiles; ++mt) {
+        int lo = n_bins, hi = -1;
+        for (int r = 0; r < 16; ++r) {
+            const int m = mt * 16 + r;
+            if (m >= n_mels) break;
+            for (int k = 0; k < n_bins; ++k)
+                if (dense[(size_t)m * n_bins + k] != 0.0f) {
+                    lo = std::min(lo, k);
+                    hi = std::max(hi, k);
+                }
+        }
+        int nsteps = 0, kstart = 0;
+        if (hi >= lo) {
+            nsteps = (hi - lo + 1 + 3) / 4;
+            kstart = std::max(0, std::min(lo, n_bins - 4 * nsteps));   // never read past bin n_bins-1
+        }
+        plan.kstart[mt] = kstart;
+        plan.nsteps[mt] = nsteps;
+        plan.aoff[mt] = (int32_t)afrag.size();
+        for (int s = 0; s < nsteps; ++s)
+            for (int l = 0; l < 64; ++l) {
+                const int m = mt * 16 + (l & 15);
+                const int k = kstart + 4 * s + (l >> 4);
+                float v = 0.0f;
+                if (m < n_mels && k < n_bins) v = dense[(size_t)m * n_bins + k] * scale;
+                afrag.push_back(v);
+            }
+    }
+    // Longest-processing-time assignment of (mel tile, frame tile) units to the 8 waves.
+    struct Unit { int mt, ft, cost; };
+    std::vector<Unit> units;
+    for (int ft = 0; ft < kFrameTiles; ++ft)
+        for (int mt = 0; mt < plan.n_mtiles; ++mt) units.push_back({mt, ft, plan.nsteps[mt] + 3});
+    std::stable_sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.cost > b.cost; });
+    int load[kWavesPerBlock] = {0};
+    for (const Unit& u : units) {
+        int best = 0;
+        for (int w = 1; w < kWavesPerBlock; ++w)
+            if (load[w] < load[best]) best = w;
+        // n_mtiles * kFrameTiles = 24 units over 8 waves: LPT never needs more than kMaxUnitsPerWave
+        plan.wave_units[best][plan.wave_nunits[best]++] = u.mt | (u.ft << 8);
+        load[best] += u.cost;
+    }
+}
+
+}  // namespace sttfe
+
+using namespace sttfe;
+
+extern "C" int sttfe_whisper_mel_bank(int n_mels, float* host_dense) {
+    if (n_mels < 1 || n_mels > 128 || !host_dense) return STTFE_E_INVALID_ARG;
+    std::vector<float> dense;
+    whisper_mel_bank(n_mels, dense);
+    std::memcpy(host_dense, dense.data(), dense.size() * sizeof(float));
+    return STTFE_OK;
+}
+
+static int whisper_tables(int n_mels, std::vector<unsigned char>& blob) {
+    if (n_mels < 1 || n_mels > 128) return STTFE_E_INVALID_ARG;
+    std::vector<float> dense, afrag;
+    whisper_mel_bank(n_mels, dense);
+    WhisperTablesHeader h;
+    std::memset(&h, 0, sizeof(h));
+    // 0.25 = the 1/4 of the two-real-frames-in-one-complex-FFT separation, folded into the bank
+    // (a power of two: bit-identical to scaling the power spectrum itself).
+    build_mel_plan(dense, n_mels, 201, 0.25f, h.plan, afrag);
+    h.magic = kWhisperMagic;
+    h.n_mels = n_mels;
+    h.afrag_floats = (int32_t)afrag.size();
+    for (int i = 0; i < 400; ++i) h.window[i] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * i / 400.0));
+    for (int k1 = 0; k1 < 20; ++k1)
+        for (int j = 0; j < 20; ++j) {
+            const int m = (j * k1) % 400;
+            h.twiddle[2 * (20 * k1 + j)] = (float)std::cos(2.0 * M_PI * m / 400.0);
+            h.twiddle[2 * (20 * k1 + j) + 1] = (float)(-std::sin(2.0 * M_PI * m / 400.0));
+        }
+    blob.resize(sizeof(h) + afrag.size() * sizeof(float));
+    std::memcpy(blob.data(), &h, sizeof(h));
+    std::memcpy(blob.data() + sizeof(h), afrag.data(), afrag.size() * sizeof(float));
+    return STTFE_OK;
+}
+
+extern "C" int sttfe_whisper_tables_bytes(int n_mels, size_t* bytes) {
+    if (!bytes) return STTFE_E_INVALID_ARG;
+    std::vector<unsigned char> blob;
+    int rc = whisper_tables(n_mels, blob);
+    if (rc != STTFE_OK) return rc;
+    *bytes = blob.size();
+    return STTFE_OK;
+}
+
+extern "C" int sttfe_whisper_tables_build(int n_mels, void* host_blob, size_t bytes) {
+    if (!host_blob) return STTFE_E_INVALID_ARG;
+    std::vector<unsigned char> blob;
+    int rc = whisper_tables(n_mels, blob);
+    if (rc != STTFE_OK) return rc;
+    if (bytes < blob.size()) return STTFE_E_TABLES;
+    std::memcpy(host_blob, blob.data(), blob.size());
+    return STTFE_OK;
+}

@@ -1,0 +1,41 @@
+// Layout of the constant "tables" blobs shared by the host builders (tables.cpp) and the kernels.
+#pragma once
+#include <stdint.h>
+
+namespace sttfe {
+
+constexpr int kMaxMelTiles = 8;          // 128 mel bins / 16 rows per MFMA tile
+constexpr int kMaxUnitsPerWave = 8;
+constexpr int kWavesPerBlock = 8;
+constexpr int kFrameTiles = 3;           // 48 frames per block iteration / 16 columns per MFMA tile
+
+constexpr uint32_t kWhisperMagic = 0x57484d31u;   // "WHM1"
+constexpr uint32_t kKaldiMagic = 0x4b414c31u;     // "KAL1"
+
+// Banded mel projection on 16x16x4 f32 MFMA tiles.  Mel tile mt covers mel rows [16 mt, 16 mt + 16)
+// and FFT bins [kstart, kstart + 4 nsteps).  afrag holds, for step s and lane l, the A operand
+// W[16 mt + (l & 15)][kstart + 4 s + (l >> 4)] (already multiplied by any constant scale).
+struct MelPlan {
+    int32_t n_mels;
+    int32_t n_mtiles;
+    int32_t n_bins;
+    int32_t reserved;
+    int32_t kstart[kMaxMelTiles];
+    int32_t nsteps[kMaxMelTiles];
+    int32_t aoff[kMaxMelTiles];                       // float offset into afrag
+    int32_t wave_nunits[kWavesPerBlock];
+    int32_t wave_units[kWavesPerBlock][kMaxUnitsPerWave];   // mt | (ft << 8)
+};
+
+struct WhisperTablesHeader {
+    uint32_t magic;
+    int32_t n_mels;
+    int32_t afrag_floats;
+    int32_t reserved;
+    MelPlan plan;
+    float window[400];          // periodic Hann
+    float twiddle[800];         // [k1][j] complex: W_400^(j k1) = (cos, -sin)(2 pi j k1 / 400)
+    // followed by: float afrag[afrag_floats]
+};
+
+}  // namespace sttfe

@@ -1,0 +1,239 @@
+"""Feature extractors with the Hugging Face call shape, running on libsttfe.so (MI355X).
+
+Drop-in for ``processor.feature_extractor`` in the reference (``src/data.py:338-358``,
+``inference.py:148-153``) and for ``TorchWhisperFeatureExtractor`` (``src/processors.py:24-246``):
+
+    fe = HipWhisperFeatureExtractor(feature_size=80)
+    feats = fe(raw_speech, sampling_rate=16000, return_tensors="pt").input_features   # (B, 80, 3000)
+
+Numerics follow the HF extractors (the parity target of BASELINE.json), NOT the HTK-scale mel of
+``src/processors.py:75-83``.  Results stay on the GPU unless ``return_tensors="np"``.
+There is no CPU path: without ``libsttfe.so`` or without a GPU these classes raise.
+"""
+from __future__ import annotations
+
+import ctypes
+from types import SimpleNamespace
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class BatchFeature(dict):
+    """dict with attribute access, like transformers.BatchFeature (``.input_features``)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def to(self, *args, **kwargs):
+        return BatchFeature({k: (v.to(*args, **kwargs) if torch.is_tensor(v) else v) for k, v in self.items()})
+
+
+def _as_clip_list(raw_speech) -> List:
+    """Normalise the accepted input forms to a list of 1-D arrays / tensors.
+
+    Accepted (src/processors.py:150,169-176; HF:...whisper.py:278-294): 1-D np.ndarray, list of floats,
+    list of 1-D arrays, 2-D np.ndarray (batch, n), list of torch tensors on any device
+    (multi-channel tensors are averaged to mono, src/processors.py:94-96).
+    """
+    if torch.is_tensor(raw_speech):
+        raw_speech = [raw_speech] if raw_speech.dim() == 1 else list(raw_speech)
+    elif isinstance(raw_speech, np.ndarray):
+        if raw_speech.ndim > 2:
+            raise ValueError("Only mono-channel audio is supported")
+        raw_speech = [raw_speech] if raw_speech.ndim == 1 else list(raw_speech)
+    elif isinstance(raw_speech, (list, tuple)):
+        if len(raw_speech) == 0:
+            return []
+        if not isinstance(raw_speech[0], (np.ndarray, list, tuple)) and not torch.is_tensor(raw_speech[0]):
+            raw_speech = [np.asarray(raw_speech, dtype=np.float32)]
+    else:
+        raise TypeError(f"unsupported raw_speech type {type(raw_speech)}")
+    return list(raw_speech)
+
+
+def pack_clips(clips: Sequence, device: torch.device, max_samples: Optional[int] = None):
+    """Concatenate clips into one device float32 buffer -> (pcm, offsets int64, lengths int32) on device.
+
+    Host arrays go through one pinned staging buffer and one async H2D copy; device tensors are
+    copied device-to-device.
+    """
+    lens, host_idx = [], []
+    for i, c in enumerate(clips):
+        if torch.is_tensor(c):
+            if c.dim() > 1:
+                c = c.float().mean(dim=0)
+                clips[i] = c
+            n = int(c.shape[-1])
+        else:
+            c = np.asarray(c, dtype=np.float32).reshape(-1)
+            clips[i] = c
+            n = c.shape[0]
+            host_idx.append(i)
+        lens.append(n if max_samples is None else min(n, max_samples))
+    # 64-sample alignment keeps every clip 256-byte aligned; 448 samples of slack after the last
+    # clip are never read (kernels bound every load by lengths[b]) but keep torch's allocator honest.
+    starts, total = [], 0
+    for n in lens:
+        starts.append(total)
+        total += (n + 63) // 64 * 64
+    pcm = torch.empty(total + 64, dtype=torch.float32, device=device)
+    if host_idx:
+        stage = torch.empty(total + 64, dtype=torch.float32, pin_memory=True)
+        sn = stage.numpy()
+        for i in host_idx:
+            sn[starts[i]:starts[i] + lens[i]] = clips[i][:lens[i]]
+        if len(host_idx) == len(clips):
+            pcm.copy_(stage, non_blocking=True)
+        else:
+            for i in host_idx:
+                pcm[starts[i]:starts[i] + lens[i]].copy_(stage[starts[i]:starts[i] + lens[i]], non_blocking=True)
+    for i, c in enumerate(clips):
+        if torch.is_tensor(c):
+            pcm[starts[i]:starts[i] + lens[i]].copy_(c.reshape(-1)[:lens[i]].to(torch.float32))
+    offsets = torch.tensor(starts, dtype=torch.int64).to(device, non_blocking=True)
+    lengths = torch.tensor(lens, dtype=torch.int32).to(device, non_blocking=True)
+    return pcm, offsets, lengths
+
+
+def _resolve_device(device) -> torch.device:
+    if device is None:
+        if not torch.cuda.is_available():
+            raise _lib.SttfeError("no GPU visible: the sttfe extractors have no CPU path")
+        return torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.SttfeError(f"device {device} is not a GPU: the sttfe extractors have no CPU path")
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
+class HipWhisperFeatureExtractor:
+    """Whisper log-mel extractor (HF ``WhisperFeatureExtractor`` call shape) on MI355X."""
+
+    model_input_names = ["input_features"]
+
+    def __init__(self, feature_size: int = 80, sampling_rate: int = 16000, hop_length: int = 160,
+                 chunk_length: int = 30, n_fft: int = 400, padding_value: float = 0.0,
+                 device: Optional[Union[str, torch.device]] = None, **kwargs):
+        if (sampling_rate, hop_length, n_fft, chunk_length) != (16000, 160, 400, 30):
+            raise ValueError("the HIP kernels implement sampling_rate=16000, hop_length=160, n_fft=400, "
+                             "chunk_length=30 (the Whisper preprocessor configuration)")
+        if not 1 <= feature_size <= 128:
+            raise ValueError("feature_size must be in [1, 128]")
+        self.feature_size = feature_size
+        self.sampling_rate = sampling_rate
+        self.hop_length = hop_length
+        self.n_fft = n_fft
+        self.win_length = n_fft
+        self.chunk_length = chunk_length
+        self.padding_value = padding_value
+        self.n_samples = chunk_length * sampling_rate
+        self.nb_max_frames = self.n_samples // hop_length
+        self.expected_frames = self.nb_max_frames
+        self._device_arg = device
+        self._tables = {}          # device index -> uint8 tensor (tables blob)
+        self._host_tables = None
+
+    # the device tensors are rebuilt lazily, so instances pickle (DataLoader workers, tests/test_dataloader.py:376-382)
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_tables"] = {}
+        return d
+
+    @property
+    def device(self) -> torch.device:
+        return _resolve_device(self._device_arg)
+
+    @property
+    def mel_filters(self) -> np.ndarray:
+        """(201, feature_size) float32 bank, same orientation as HF's ``mel_filters``."""
+        dense = np.empty((self.feature_size, 201), dtype=np.float32)
+        _lib.check(_lib.lib().sttfe_whisper_mel_bank(self.feature_size, dense.ctypes.data_as(ctypes.c_void_p)))
+        return dense.T.copy()
+
+    def _tables_on(self, device: torch.device) -> torch.Tensor:
+        t = self._tables.get(device.index)
+        if t is None:
+            if self._host_tables is None:
+                L = _lib.lib()
+                n = ctypes.c_size_t()
+                _lib.check(L.sttfe_whisper_tables_bytes(self.feature_size, ctypes.byref(n)))
+                host = torch.empty(n.value, dtype=torch.uint8)
+                _lib.check(L.sttfe_whisper_tables_build(self.feature_size, _lib.ptr(host), n.value))
+                self._host_tables = host
+            t = self._host_tables.to(device)
+            self._tables[device.index] = t
+        return t
+
+    def extract(self, pcm: torch.Tensor, offsets: torch.Tensor, lengths: torch.Tensor,
+                mask_table: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Device-resident entry: packed PCM + per-clip offsets/lengths -> (B, M, 3000) float32."""
+        device = pcm.device
+        B = int(offsets.shape[0])
+        L = _lib.lib()
+        if out is None:
+            out = torch.empty((B, self.feature_size, self.nb_max_frames), dtype=torch.float32, device=device)
+        ws_bytes = ctypes.c_size_t()
+        _lib.check(L.sttfe_whisper_workspace_bytes(B, ctypes.byref(ws_bytes)))
+        ws = torch.empty(max(ws_bytes.value, 1), dtype=torch.uint8, device=device)
+        n_masks = 0
+        if mask_table is not None:
+            assert mask_table.dtype == torch.int32 and mask_table.dim() == 3 and mask_table.shape[2] == 3
+            mask_table = mask_table.to(device).contiguous()
+            n_masks = int(mask_table.shape[1])
+        stream = torch.cuda.current_stream(device).cuda_stream
+        with torch.cuda.device(device):
+            _lib.check(L.sttfe_whisper_logmel(_lib.ptr(pcm), _lib.ptr(offsets), _lib.ptr(lengths), B,
+                                              self.feature_size, self.nb_max_frames,
+                                              _lib.ptr(self._tables_on(device)), _lib.ptr(out),
+                                              _lib.ptr(mask_table), n_masks, _lib.ptr(ws), ws.numel(),
+                                              ctypes.c_void_p(stream)), "sttfe_whisper_logmel")
+        return out
+
+    def __call__(self, raw_speech, sampling_rate: Optional[int] = None, return_tensors: Optional[str] = "pt",
+                 padding=True, truncation: bool = True, max_length: Optional[int] = None,
+                 mask_table: Optional[torch.Tensor] = None, **kwargs):
+        if sampling_rate is not None and sampling_rate != self.sampling_rate:
+            raise ValueError(
+                f"The model corresponding to this feature extractor: {self.__class__.__name__} was trained using a "
+                f"sampling rate of {self.sampling_rate}. Please make sure that the provided `raw_speech` input was "
+                f"sampled with {self.sampling_rate} and not {sampling_rate}.")
+        clips = _as_clip_list(raw_speech)
+        device = self.device
+        if not clips:
+            feats = torch.empty((0, self.feature_size, self.nb_max_frames), dtype=torch.float32, device=device)
+        else:
+            pcm, offsets, lengths = pack_clips(clips, device, self.n_samples)
+            feats = self.extract(pcm, offsets, lengths, mask_table)
+        if return_tensors == "np":
+            feats = feats.cpu().numpy()
+        return BatchFeature({"input_features": feats})
+
+
+class TorchWhisperFeatureExtractor(HipWhisperFeatureExtractor):
+    """Name/signature-compatible stand-in for ``src/processors.py:TorchWhisperFeatureExtractor``.
+
+    Same constructor arguments and ``__call__(raw_speech, sampling_rate, return_tensors, padding)``;
+    returns a ``SimpleNamespace(input_features=...)`` like the reference (src/processors.py:241-246)
+    and raises ``ValueError`` on a wrong sampling rate (src/processors.py:165-166).  Only the fixed
+    30-second form (``padding=True``) is implemented; numerics are HF's (slaney mel scale).
+    """
+
+    def __call__(self, raw_speech, sampling_rate: Optional[int] = None, return_tensors: Optional[str] = "pt",
+                 padding: Optional[bool] = True):
+        if sampling_rate is None:
+            sampling_rate = self.sampling_rate
+        if sampling_rate != self.sampling_rate:
+            raise ValueError(f"Expected sampling_rate={self.sampling_rate}, got {sampling_rate}. Resample beforehand.")
+        if not padding:
+            raise NotImplementedError("padding=False (variable-length output) is not implemented by the HIP extractor")
+        out = super().__call__(raw_speech, sampling_rate=sampling_rate, return_tensors=return_tensors)
+        return SimpleNamespace(input_features=out["input_features"])

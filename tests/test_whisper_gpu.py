@@ -1,0 +1,106 @@
+"""GPU parity of the Whisper log-mel path (row W) through the C ABI: HIP vs oracle vs HF goldens.
+
+Tolerance: BASELINE.json north_star -- max abs error <= 1e-4 on the normalised log-mel.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, whisper_golden_cases
+from speech_to_text_amd.synth import synth_batch, synth_clip
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def fe80():
+    from speech_to_text_amd.processors import HipWhisperFeatureExtractor
+    return HipWhisperFeatureExtractor(80, device="cuda:0")
+
+
+@pytest.fixture(scope="module")
+def fe128():
+    from speech_to_text_amd.processors import HipWhisperFeatureExtractor
+    return HipWhisperFeatureExtractor(128, device="cuda:0")
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_matches_hf_goldens(n_mels, fe80, fe128):
+    fe = fe80 if n_mels == 80 else fe128
+    cases = list(whisper_golden_cases(n_mels))
+    # one batched call with every golden clip (ragged lengths, zeros, tiny clip)
+    out = fe([c[1] for c in cases], sampling_rate=16000, return_tensors="pt").input_features
+    assert out.shape == (len(cases), n_mels, 3000) and out.dtype == torch.float32 and out.is_cuda
+    out = out.cpu().numpy()
+    for i, (name, _, expected) in enumerate(cases):
+        err = float(np.max(np.abs(out[i] - expected)))
+        assert err <= TOL, (name, err)
+    # single-clip calls give the same numbers as the batched call
+    single = fe(cases[2][1], sampling_rate=16000, return_tensors="np").input_features
+    assert single.shape == (1, n_mels, 3000)
+    assert np.array_equal(single[0], out[2])
+
+
+def test_full_31s_truncated(fe80):
+    z = load_golden("whisper_80_full31s.npz")
+    clip = synth_clip(np.random.default_rng(int(z["seed"])), int(z["n_samples"]), zero_block=True)
+    out = fe80(clip, sampling_rate=16000).input_features[0].cpu().numpy()
+    assert float(np.max(np.abs(out - z["out"]))) <= TOL
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_matches_oracle_on_seeded_batch(n_mels, fe80, fe128):
+    from oracle.whisper import whisper_features
+    fe = fe80 if n_mels == 80 else fe128
+    lengths = [480000, 480000, 82400, 16000, 479999, 240123, 199, 200, 201, 1, 560]
+    clips = synth_batch(101, lengths)
+    got = fe(clips, sampling_rate=16000).input_features.cpu().numpy()
+    exp = whisper_features(clips, n_mels)
+    err = np.abs(got - exp).reshape(len(clips), -1).max(axis=1)
+    assert float(err.max()) <= TOL, err
+
+
+def test_input_forms_and_errors(fe80):
+    clip = synth_clip(np.random.default_rng(5), 8000, zero_block=False)
+    ref = fe80(clip, sampling_rate=16000).input_features
+    assert torch.equal(fe80(clip.tolist(), sampling_rate=16000).input_features, ref)
+    assert torch.equal(fe80([torch.from_numpy(clip).cuda()], sampling_rate=16000).input_features, ref)
+    assert torch.equal(fe80(np.stack([clip, clip]), sampling_rate=16000).input_features[1], ref[0])
+    stereo = torch.from_numpy(np.stack([clip, clip]))
+    assert torch.allclose(fe80([stereo], sampling_rate=16000).input_features, ref, atol=1e-6)
+    with pytest.raises(ValueError):
+        fe80(clip, sampling_rate=8000)
+    from speech_to_text_amd.processors import TorchWhisperFeatureExtractor
+    tfe = TorchWhisperFeatureExtractor(device="cuda:0")
+    ns = tfe([torch.from_numpy(clip)], sampling_rate=16000, return_tensors="pt", padding=True)
+    assert torch.equal(ns.input_features, ref)
+    with pytest.raises(ValueError, match="Expected sampling_rate=16000"):
+        tfe([clip], sampling_rate=44100)
+
+
+def test_scale_linearity_property_full_size(fe80):
+    """Size-independent property at the BASELINE batch shape: scaling a clip by 2**k shifts the
+    un-clamped log-mel by exactly k*log10(4)/4 (power-of-two scaling is exact in every stage)."""
+    clips = synth_batch(7, [480000] * 8)
+    a = fe80(clips, sampling_rate=16000).input_features
+    b = fe80([c * np.float32(0.25) for c in clips], sampling_rate=16000).input_features
+    shift = 2 * np.log10(0.25) / 4.0
+    assert float((b - (a + shift)).abs().max()) <= 2e-6
+
+
+def test_specaugment_masks_fused(fe80):
+    clips = synth_batch(9, [48000, 32000, 16000])
+    base = fe80(clips, sampling_rate=16000).input_features
+    tbl = torch.tensor([[[1, 100, 117], [1, 2990, 3000], [0, 5, 20], [0, 70, 80]],
+                        [[1, 0, 0], [1, 0, 0], [0, 0, 0], [0, 0, 0]],
+                        [[1, 0, 19], [1, 40, 41], [0, 0, 1], [0, 79, 80]]], dtype=torch.int32)
+    got = fe80(clips, sampling_rate=16000, mask_table=tbl).input_features
+    exp = base.clone()
+    for b in range(3):
+        for axis, s, e in tbl[b].tolist():
+            if axis == 1:
+                exp[b, :, s:e] = 0.0
+            else:
+                exp[b, s:e, :] = 0.0
+    assert torch.equal(got, exp)
