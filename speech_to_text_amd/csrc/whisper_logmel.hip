@@ -130,7 +130,8 @@ __global__ __launch_bounds__(kThreads, 4) void whisper_stft_mel_kernel(
 #pragma unroll
             for (int m = 0; m < 28; ++m) {
                 int idx = base + 20 * m;
-                idx = idx < 0 ? -idx : idx;                       // reflect padding (center=True)
+                idx = idx < 0 ? -idx : idx;                       // reflect padding (center=True) ...
+                idx = idx >= kMaxSamples ? 2 * (kMaxSamples - 1) - idx : idx;   // ... of the 30 s buffer
                 raw[m] = (idx < n_valid) ? x[idx] : 0.0f;         // zero padding to 30 s
             }
         }

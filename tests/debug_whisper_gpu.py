@@ -16,5 +16,5 @@ for n_mels in (80, 128):
     i = np.unravel_index(np.argmax(d), d.shape)
     print("worst at", i, got[i], exp[i])
     print("nan", np.isnan(got).sum())
-    print("err by frame block (clip0):", d[0].max(axis=0).reshape(-1, 48*5)[:, :].max(axis=1)[:14])
+    print("err by frame block (clip0):", d[0].max(axis=0)[:2880].reshape(-1, 240).max(axis=1))
     print("err by mel (clip0):", d[0].max(axis=1)[::8])
