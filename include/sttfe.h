@@ -42,6 +42,8 @@ extern "C" {
 
 int sttfe_version(void);
 const char* sttfe_strerror(int code);
+/* HIP error text behind the calling thread's last STTFE_E_LAUNCH ("" if none). */
+const char* sttfe_last_error_detail(void);
 
 /* ---------------------------------------------------------------- Whisper log-mel (row W) ----
  * Replaces processor.feature_extractor(audio_np, sampling_rate=16000, return_tensors="pt")
@@ -72,6 +74,22 @@ int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, const int32_t
                          int batch, int n_mels, int n_frames, const void* dev_tables,
                          float* out, const int32_t* mask_tbl, int n_masks,
                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* Clips per launch pair of sttfe_whisper_logmel (default 96): kernel 1's output for a chunk should
+ * still be in the 256 MiB Infinity Cache when the clamp kernel re-reads it.  Tuning knob. */
+int sttfe_set_whisper_chunk(int clips);
+
+/* ------------------------------------------------------------- measurement support -----------
+ * No counterpart in the reference.  Optional per-kernel timing with HIP events recorded on the
+ * launch stream around every kernel launch (used by bench.py for the roofline figure).
+ * sttfe_timing_enable(capacity) allocates `capacity` event pairs (0 disables and frees them);
+ * sttfe_timing_query(name, ...) returns the summed duration and launch count of one kernel
+ * ("whisper_stft_mel", "whisper_clamp_mask", "kaldi_fbank", "kaldi_cmvn", "resample_peak",
+ * "normalize_trim") since the last enable/reset; it synchronises on the recorded events.
+ */
+int sttfe_timing_enable(int capacity);
+int sttfe_timing_reset(void);
+int sttfe_timing_query(const char* name, double* total_ms, int* launches);
 
 #ifdef __cplusplus
 }

@@ -3,6 +3,11 @@ from __future__ import annotations
 
 import ctypes
 import os
+
+# torch must be imported BEFORE libsttfe.so is loaded: torch ships its own libamdhip64.so.7 and the two
+# must share ONE HIP runtime (streams and device pointers cross the boundary).  Loading ours first
+# would bind /opt/rocm's runtime instead and HIP then reports "no ROCm-capable device".
+import torch  # noqa: F401
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -20,6 +25,7 @@ def _declare(lib):
     lib.sttfe_version.restype = c_int
     lib.sttfe_strerror.restype = c_char_p
     lib.sttfe_strerror.argtypes = [c_int]
+    lib.sttfe_last_error_detail.restype = c_char_p
     sigs = {
         "sttfe_whisper_tables_bytes": [c_int, POINTER(c_size_t)],
         "sttfe_whisper_tables_build": [c_int, p, c_size_t],
@@ -27,6 +33,9 @@ def _declare(lib):
         "sttfe_whisper_workspace_bytes": [c_int, POINTER(c_size_t)],
         "sttfe_whisper_logmel": [p, p, p, c_int, c_int, c_int, p, p, p, c_int, p, c_size_t, p],
         "sttfe_set_whisper_chunk": [c_int],
+        "sttfe_timing_enable": [c_int],
+        "sttfe_timing_reset": [],
+        "sttfe_timing_query": [c_char_p, POINTER(ctypes.c_double), POINTER(c_int)],
         "sttfe_kaldi_tables_bytes": [c_int, POINTER(c_size_t)],
         "sttfe_kaldi_tables_build": [c_int, p, c_size_t],
         "sttfe_kaldi_mel_bank": [c_int, p],
@@ -60,7 +69,9 @@ def lib():
 def check(code: int, what: str = "sttfe"):
     if code != 0:
         msg = lib().sttfe_strerror(code)
-        raise SttfeError(f"{what} failed: {msg.decode() if msg else code} ({code})")
+        detail = lib().sttfe_last_error_detail()
+        raise SttfeError(f"{what} failed: {msg.decode() if msg else code} ({code})"
+                         + (f" [{detail.decode()}]" if detail else ""))
 
 
 def ptr(t):

@@ -14,3 +14,7 @@ extern "C" const char* sttfe_strerror(int code) {
         default: return "unknown sttfe error";
     }
 }
+
+// Detail of the last STTFE_E_LAUNCH (the HIP error string), per thread.
+namespace sttfe { thread_local char g_last_detail[256] = ""; }
+extern "C" const char* sttfe_last_error_detail(void) { return sttfe::g_last_detail; }

@@ -31,6 +31,7 @@
 #include "../../include/sttfe.h"
 #include "fft_core.h"
 #include "tables.h"
+#include "timing.h"
 
 namespace sttfe {
 
@@ -295,7 +296,8 @@ extern "C" int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, co
     if (workspace_bytes < need) return STTFE_E_WORKSPACE;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     unsigned* keys = reinterpret_cast<unsigned*>(workspace);
-    if (hipMemsetAsync(keys, 0, need, stream) != hipSuccess) return STTFE_E_LAUNCH;
+    (void)hipGetLastError();      // drop any stale error left by earlier, unrelated HIP calls of this thread
+    if (hip_failed(hipMemsetAsync(keys, 0, need, stream), "hipMemsetAsync(max keys)")) return STTFE_E_LAUNCH;
 
     const int n_tiles = (n_frames + kTileFrames - 1) / kTileFrames;
     const int tiles_per_block = 4;
@@ -303,14 +305,20 @@ extern "C" int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, co
     const auto* tab = reinterpret_cast<const WhisperTablesHeader*>(dev_tables);
     for (int c0 = 0; c0 < batch; c0 += g_whisper_chunk) {
         const int nc = (batch - c0 < g_whisper_chunk) ? batch - c0 : g_whisper_chunk;
-        hipLaunchKernelGGL(whisper_stft_mel_kernel, dim3(blocks_x, nc), dim3(kThreads), 0, stream,
-                           pcm, offsets, lengths, c0, n_mels, n_frames, tab, out, keys, tiles_per_block);
+        {
+            ScopedTiming t(kTimeWhisperStftMel, stream);
+            hipLaunchKernelGGL(whisper_stft_mel_kernel, dim3(blocks_x, nc), dim3(kThreads), 0, stream,
+                               pcm, offsets, lengths, c0, n_mels, n_frames, tab, out, keys, tiles_per_block);
+        }
         const int total4 = n_mels * n_frames / 4;
         int bx = (total4 + 255) / 256;
         if (bx > 32) bx = 32;
-        hipLaunchKernelGGL(whisper_clamp_mask_kernel, dim3(bx, nc), dim3(256), 0, stream, out, keys, c0,
-                           n_mels, n_frames, mask_tbl, n_masks);
+        {
+            ScopedTiming t(kTimeWhisperClamp, stream);
+            hipLaunchKernelGGL(whisper_clamp_mask_kernel, dim3(bx, nc), dim3(256), 0, stream, out, keys, c0,
+                               n_mels, n_frames, mask_tbl, n_masks);
+        }
     }
-    if (hipGetLastError() != hipSuccess) return STTFE_E_LAUNCH;
+    if (hip_failed(hipGetLastError(), "whisper kernel launch")) return STTFE_E_LAUNCH;
     return STTFE_OK;
 }

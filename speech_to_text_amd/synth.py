@@ -41,3 +41,31 @@ def common_voice_lengths(rng: np.random.Generator, batch: int, sample_rate: int 
     """Clip durations ~ N(5.15, 1.77) s clipped to [1.08, 10.58] (reference notebooks/01_eda.ipynb stats)."""
     d = np.clip(rng.normal(5.15, 1.77, size=batch), 1.08, 10.58)
     return (d * sample_rate).astype(np.int64)
+
+
+def synth_batch_device(seed: int, batch: int, n_samples: int, device, sample_rate: int = 16000,
+                       chunk: int = 64):
+    """Same signal family generated on the GPU with torch -> (batch, n_samples) float32.
+
+    Used by bench.py for the BASELINE-sized inputs (1024 x 480 000 samples would take minutes with
+    NumPy).  Parameters come from a seeded host generator; the noise from a seeded device generator.
+    """
+    import torch
+    rng = np.random.default_rng(seed)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    out = torch.empty((batch, n_samples), dtype=torch.float32, device=device)
+    t = torch.arange(n_samples, dtype=torch.float64, device=device) / sample_rate
+    for b0 in range(0, batch, chunk):
+        nb = min(chunk, batch - b0)
+        x = torch.zeros((nb, n_samples), dtype=torch.float64, device=device)
+        for _ in range(3):
+            a = torch.tensor(rng.uniform(0.05, 0.4, nb), device=device)[:, None]
+            f0 = torch.tensor(rng.uniform(80.0, 3000.0, nb), device=device)[:, None]
+            k = torch.tensor(rng.uniform(-200.0, 200.0, nb), device=device)[:, None]
+            phi = torch.tensor(rng.uniform(0.0, 2 * np.pi, nb), device=device)[:, None]
+            x += a * torch.sin(2 * np.pi * (f0 + k * t[None, :]) * t[None, :] + phi)
+        sigma = torch.tensor(rng.uniform(0.002, 0.05, nb), device=device)[:, None]
+        x += sigma * torch.randn((nb, n_samples), dtype=torch.float64, device=device, generator=gen)
+        out[b0:b0 + nb] = x.clamp_(-1.0, 1.0).to(torch.float32)
+    return out
