@@ -75,6 +75,35 @@ int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, const int32_t
                          float* out, const int32_t* mask_tbl, int n_masks,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------- Speech2Text Kaldi fbank + utterance CMVN (row K) ----
+ * Replaces processor.feature_extractor(audio_np, sampling_rate=16000, return_tensors="pt",
+ * truncation=..., max_length=...) for Speech2TextProcessor: src/data.py:346-358, plus the time
+ * padding / attention mask of the collator, src/data.py:468-487.  Arithmetic =
+ * HF:models/speech_to_text/feature_extraction_speech_to_text.py:104-163 and HF:audio_utils.py:953-1017.
+ */
+#define STTFE_KALDI_NO_CMVN 1      /* flags: store ln(mel) without the (x - mean) / std step */
+
+int sttfe_kaldi_tables_bytes(int n_mels, size_t* bytes);
+int sttfe_kaldi_tables_build(int n_mels, void* host_blob, size_t bytes);
+int sttfe_kaldi_mel_bank(int n_mels, float* host_dense /* [n_mels][257] */);
+int sttfe_kaldi_workspace_bytes(int batch, int n_mels, size_t* bytes);
+
+/*
+ * Frames of clip b: T_b = min(1 + (lengths[b] - 400) / 160, max_frames if > 0, t_max); 0 if shorter
+ * than 400 samples.
+ * out        : device float32 [batch][t_max][n_mels] (time-major, what Speech2Text consumes);
+ *              rows t >= T_b are 0.0 (padding_value).
+ * attn_mask  : device [batch][t_max] of int32 (attn_mask_bytes = 4, the HF extractor's dtype) or
+ *              int64 (8, the collator's torch.long, src/data.py:484); NULL to skip.
+ * mask_tbl   : as for sttfe_whisper_logmel; axis STTFE_AXIS_FREQ indexes the mel bin,
+ *              STTFE_AXIS_TIME the frame; applied after CMVN.
+ */
+int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, const int32_t* lengths,
+                           int batch, int n_mels, int t_max, int max_frames, int flags,
+                           const void* dev_tables, float* out, void* attn_mask, int attn_mask_bytes,
+                           const int32_t* mask_tbl, int n_masks,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* Clips per launch pair of sttfe_whisper_logmel (default 96): kernel 1's output for a chunk should
  * still be in the 256 MiB Infinity Cache when the clamp kernel re-reads it.  Tuning knob. */
 int sttfe_set_whisper_chunk(int clips);

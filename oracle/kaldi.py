@@ -62,12 +62,12 @@ def num_frames(n_samples: int) -> int:
     return 1 + (n_samples - FRAME) // HOP
 
 
-def kaldi_fbank(wave: np.ndarray, n_mels: int = 80) -> np.ndarray:
-    """1-D float32 waveform in [-1, 1] -> (T, n_mels) float32 log-mel (natural log)."""
+def kaldi_power(wave: np.ndarray) -> np.ndarray:
+    """1-D float32 waveform in [-1, 1] -> (T, 257) float64 power spectrum of the Kaldi frames."""
     x = (np.asarray(wave, dtype=np.float32).reshape(-1) * (2 ** 15)).astype(np.float64)
     T = num_frames(x.shape[0])
     if T == 0:
-        return np.zeros((0, n_mels), dtype=np.float32)
+        return np.zeros((0, N_BINS), dtype=np.float64)
     idx = np.arange(FRAME)[None, :] + HOP * np.arange(T)[:, None]
     buf = x[idx]                                                  # (T, 400) float64
     buf = buf - buf.mean(axis=1, keepdims=True)                   # remove_dc_offset (:979-980)
@@ -76,7 +76,14 @@ def kaldi_fbank(wave: np.ndarray, n_mels: int = 80) -> np.ndarray:
     pre[:, 0] *= 1.0 - 0.97
     pre *= povey_window()[None, :]
     spec = np.fft.rfft(pre, n=FFT, axis=1).astype(np.complex64)   # stored as complex64 (:966)
-    power = np.abs(spec, dtype=np.float64) ** 2.0                 # (:993)
+    return np.abs(spec, dtype=np.float64) ** 2.0                  # (:993)
+
+
+def kaldi_fbank(wave: np.ndarray, n_mels: int = 80) -> np.ndarray:
+    """1-D float32 waveform in [-1, 1] -> (T, n_mels) float32 log-mel (natural log)."""
+    power = kaldi_power(wave)
+    if power.shape[0] == 0:
+        return np.zeros((0, n_mels), dtype=np.float32)
     mel = np.maximum(MEL_FLOOR, power @ mel_filter_bank_kaldi(n_mels))   # (:998)
     return np.log(mel).astype(np.float32)                         # (:1002,1015)
 

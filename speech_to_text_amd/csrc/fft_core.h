@@ -131,4 +131,33 @@ STTFE_HD void dft16(const cf (&in)[16], cf (&out)[16]) {
     }
 }
 
+// 32-point DFT, natural order in -> out: radix-2 split into two 16-point DFTs.
+STTFE_HD void dft32(const cf (&in)[32], cf (&out)[32]) {
+    cf e[16], o[16], E[16], O[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        e[i] = in[2 * i];
+        o[i] = in[2 * i + 1];
+    }
+    dft16(e, E);
+    dft16(o, O);
+    // W32^k = exp(-2 pi i k / 32), k = 0..15
+    constexpr float CW[16] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f,
+                              0.70710678118654752f, 0.55557023301960218f, 0.38268343236508977f,
+                              0.19509032201612825f, 0.0f, -0.19509032201612825f, -0.38268343236508977f,
+                              -0.55557023301960218f, -0.70710678118654752f, -0.83146961230254524f,
+                              -0.92387953251128674f, -0.98078528040323043f};
+    constexpr float SW[16] = {0.0f, 0.19509032201612825f, 0.38268343236508977f, 0.55557023301960218f,
+                              0.70710678118654752f, 0.83146961230254524f, 0.92387953251128674f,
+                              0.98078528040323043f, 1.0f, 0.98078528040323043f, 0.92387953251128674f,
+                              0.83146961230254524f, 0.70710678118654752f, 0.55557023301960218f,
+                              0.38268343236508977f, 0.19509032201612825f};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const cf t = (k == 0) ? O[0] : (k == 8 ? mul_mi(O[8]) : cmul(O[k], cf{CW[k], -SW[k]}));
+        out[k] = E[k] + t;
+        out[k + 16] = E[k] - t;
+    }
+}
+
 }  // namespace sttfe

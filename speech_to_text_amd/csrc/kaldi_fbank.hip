@@ -1,0 +1,333 @@
+// Speech2Text front-end for gfx950 (MI355X): Kaldi-style 80-bin log-mel fbank + utterance CMVN.
+//
+// Replaces HF Speech2TextFeatureExtractor._extract_fbank_features + utterance_cmvn
+// (HF:models/speech_to_text/feature_extraction_speech_to_text.py:104-163, framing loop
+// HF:audio_utils.py:953-1017) as reached from the reference at src/data.py:346-358, plus the
+// zero padding / attention mask / transpose of the collator (src/data.py:468-496).
+//
+// Kernel 1 (kaldi_fbank): one 256-thread workgroup (4 waves) per 32-frame tile of one clip.
+//   * snip-edges frames of 400 samples, hop 160; per frame: remove DC, pre-emphasis 0.97, Povey
+//     window, zero-pad to 512 (all fused into the load stage; the x * 2^15 scaling is folded into
+//     the mel bank as 2^30).
+//   * a wave owns 8 frames = 4 pairs; two real frames are packed into one complex 512-point DFT,
+//     factored 16 x 32: stage 1 (two rounds of 2 pairs x 32 lanes) = 16-point DFT over n1 of
+//     z[32 n1 + n2], twiddle W_512^(n2 k1), conflict-free LDS slab [pair][k1][n2] (row stride 33,
+//     pair stride 528 float2); stage 2 (4 pairs x 16 lanes) = 32-point DFT over n2.  Lane k1 then
+//     holds Z[k1 + 16 k2]; spectra separated with one cross-lane exchange (k1 <-> 16 - k1).
+//   * |.|^2 for bins 0..256 -> [frame][bin] LDS panel (row stride 258) aliasing the slabs.
+//   * banded mel projection on v_mfma_f32_16x16x4_f32 (frames as rows, mel bins as columns, so the
+//     (B, T, 80) time-major output is written in 64-byte runs), ln(max(mel, eps)) epilogue, raw
+//     log-mel stored; per-clip per-bin sum / sum of squares accumulated with f64 atomics.
+// Kernel 2 (kaldi_cmvn): (x - mean) / std per clip and bin over the valid frames, padded rows <- 0,
+//   SpecAugment masks <- 0, attention mask written (int32 or int64).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sttfe.h"
+#include "fft_core.h"
+#include "tables.h"
+#include "timing.h"
+
+namespace sttfe {
+
+namespace kaldi {
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int kTileFrames = 32;
+constexpr int kFramesPerWave = 8;
+constexpr int kHop = 160;
+constexpr int kFrame = 400;
+constexpr int kRowStride = 33;             // float2 units, [k1][n2] rows
+constexpr int kPairStride = 528;           // float2 units per pair (== 16 mod 32)
+constexpr int kSlabPerWave = 4 * kPairStride;
+constexpr int kPStride = 258;              // floats per frame row of the power panel (== 2 mod 32)
+constexpr int kLdsBytes = kWaves * kSlabPerWave * 8;     // 67584 B -> 2 workgroups per CU
+static_assert(kTileFrames * kPStride * 4 <= kLdsBytes, "power panel must fit inside the FFT slabs");
+constexpr float kMelFloor = 1.1920928955078125e-07f;
+}  // namespace kaldi
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wave_lds_sync2() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int kaldi_num_frames(int n, int max_frames, int t_max) {
+    int t = n >= kaldi::kFrame ? 1 + (n - kaldi::kFrame) / kaldi::kHop : 0;
+    if (max_frames > 0 && t > max_frames) t = max_frames;
+    return t > t_max ? t_max : t;
+}
+
+__global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
+    const float* __restrict__ pcm, const int64_t* __restrict__ offsets,
+    const int32_t* __restrict__ lengths, int n_mels, int t_max, int max_frames,
+    const KaldiTablesHeader* __restrict__ tab, float* __restrict__ out, double* __restrict__ stats,
+    int tiles_per_block) {
+    using namespace kaldi;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsBytes];
+    cf* slab_all = reinterpret_cast<cf*>(smem);
+    float* panel = reinterpret_cast<float*>(smem);
+
+    const int clip = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* __restrict__ x = pcm + offsets[clip];
+    const int n_valid = lengths[clip];
+    const int T = kaldi_num_frames(n_valid, max_frames, t_max);
+    const int n_tiles = (T + kTileFrames - 1) / kTileFrames;
+    const int tile_begin = blockIdx.x * tiles_per_block;
+    const int tile_end = min(tile_begin + tiles_per_block, n_tiles);
+    if (tile_begin >= tile_end) return;
+
+    const float* __restrict__ afrag = reinterpret_cast<const float*>(tab + 1);
+    const MelPlan& plan = tab->plan;
+    const cf* __restrict__ tw_tab = reinterpret_cast<const cf*>(tab->twiddle);
+    cf* slab_w = slab_all + wave * kSlabPerWave;
+    float* __restrict__ out_clip = out + (size_t)clip * t_max * n_mels;
+    double* __restrict__ st = stats + (size_t)clip * 2 * n_mels;
+
+    // stage-1 lane roles: half-wave h = pair within the round, n2 = column
+    const int h = lane >> 5, n2 = lane & 31;
+    // stage-2 lane roles: q = pair, k1 = row
+    const int q = lane >> 4, k1 = lane & 15;
+    const int partner = q * 16 + ((16 - k1) & 15);
+
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        const int t0 = tile * kTileFrames;
+        // last sample any lane of this tile may touch (frame b of the last pair, m = 17, n2 = 31)
+        const bool interior = (kHop * (t0 + kTileFrames - 1) + kFrame + 16 <= n_valid);
+        int keep = 0;
+        asm volatile("" : "+v"(keep));      // keep table loads inside the loop
+
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int pair = 2 * r + h;
+            const int fa = t0 + wave * kFramesPerWave + 2 * pair;
+            const int base = kHop * fa + n2;
+            float raw[18], prv[18];
+            if (interior) {
+#pragma unroll
+                for (int m = 0; m < 18; ++m) {
+                    const int idx = base + 32 * m;
+                    raw[m] = x[idx];
+                    prv[m] = x[idx > 0 ? idx - 1 : 0];
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 18; ++m) {
+                    const int idx = base + 32 * m;
+                    raw[m] = (idx < n_valid) ? x[idx] : 0.0f;
+                    prv[m] = (idx - 1 < n_valid) ? x[idx > 0 ? idx - 1 : 0] : 0.0f;
+                }
+            }
+            // per-frame mean over n = 0..399 (n = 32 n1 + n2; n1 = 12 only for n2 < 16)
+            float sa = 0.f, sb = 0.f;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                sa += raw[i];
+                sb += raw[i + 5];
+            }
+            const bool lowcol = n2 < 16;
+            sa += lowcol ? raw[12] : 0.f;
+            sb += lowcol ? raw[17] : 0.f;
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) {
+                sa += __shfl_xor(sa, off, 64);
+                sb += __shfl_xor(sb, off, 64);
+            }
+            const float mu_a = sa * (1.0f / 400.0f), mu_b = sb * (1.0f / 400.0f);
+            cf v[16], y[16];
+#pragma unroll
+            for (int i = 0; i < 13; ++i) {
+                const float w = tab->window[32 * i + (i == 12 ? (n2 & 15) : n2) + keep];
+                // (x[n] - mu) - 0.97 (x[n-1] - mu); n == 0: 0.03 (x[0] - mu)
+                float ea = (raw[i] - 0.97f * prv[i]) - 0.03f * mu_a;
+                float eb = (raw[i + 5] - 0.97f * prv[i + 5]) - 0.03f * mu_b;
+                if (i == 0 && n2 == 0) {
+                    ea = 0.03f * (raw[0] - mu_a);
+                    eb = 0.03f * (raw[5] - mu_b);
+                }
+                if (i == 12 && !lowcol) {
+                    ea = 0.f;
+                    eb = 0.f;
+                }
+                v[i] = cf{ea * w, eb * w};
+            }
+            v[13] = v[14] = v[15] = cf{0.f, 0.f};
+            dft16(v, y);
+            cf* slab = slab_w + pair * kPairStride + n2;
+            slab[0] = y[0];
+#pragma unroll
+            for (int kk = 1; kk < 16; ++kk) slab[kk * kRowStride] = cmul(y[kk], tw_tab[32 * kk + n2 + keep]);
+        }
+        wave_lds_sync2();
+
+        // ---------------- stage 2: 32-point DFT over n2 ------------------------------------------
+        float pa[17], pb[17];
+        {
+            cf v[32], y[32];
+            const cf* row = slab_w + q * kPairStride + k1 * kRowStride;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) v[i] = row[i];
+            dft32(v, y);          // y[k2] = Z[k1 + 16 k2]
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) {
+                float qr = __shfl(y[31 - k2].x, partner, 64);
+                float qi = __shfl(y[31 - k2].y, partner, 64);
+                if (k1 == 0) {
+                    qr = (k2 == 0) ? y[0].x : y[32 - k2].x;
+                    qi = (k2 == 0) ? y[0].y : y[32 - k2].y;
+                }
+                const float sr = y[k2].x + qr, dr = y[k2].x - qr;
+                const float si = y[k2].y + qi, di = y[k2].y - qi;
+                pa[k2] = sr * sr + di * di;
+                pb[k2] = si * si + dr * dr;
+            }
+            pa[16] = 4.0f * y[16].x * y[16].x;     // bin 256 (k1 == 0 only)
+            pb[16] = 4.0f * y[16].y * y[16].y;
+        }
+        __syncthreads();
+        {
+            float* row = panel + (wave * kFramesPerWave + 2 * q) * kPStride + k1;
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) {
+                row[16 * k2] = pa[k2];
+                row[kPStride + 16 * k2] = pb[k2];
+            }
+            if (k1 == 0) {
+                row[256] = pa[16];
+                row[kPStride + 256] = pb[16];
+            }
+        }
+        __syncthreads();
+
+        // ---------------- banded mel projection (frames x mels) + ln + CMVN statistics -----------
+        const int nu = plan.wave_nunits[wave];
+        for (int u = 0; u < nu; ++u) {
+            const int code = plan.wave_units[wave][u];
+            const int mt = code & 0xff, ft = code >> 8;
+            const int ks = plan.kstart[mt], ns = plan.nsteps[mt];
+            const float* __restrict__ w_ptr = afrag + plan.aoff[mt] + lane;
+            const float* p_ptr = panel + (ft * 16 + (lane & 15)) * kPStride + ks + (lane >> 4);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < ns; ++s)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p_ptr[4 * s], w_ptr[s * 64], acc, 0, 0, 0);
+            const int mel = mt * 16 + (lane & 15);
+            const int frame0 = t0 + ft * 16 + (lane >> 4) * 4;
+            double s1 = 0.0, s2 = 0.0;     // f64 from the first add: var = E[x^2] - mean^2 cancels ~3 digits
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int frame = frame0 + r;
+                if (mel < n_mels && frame < T) {
+                    const float lg = __log2f(fmaxf(acc[r], kMelFloor)) * 0.69314718055994531f;
+                    out_clip[(size_t)frame * n_mels + mel] = lg;
+                    s1 += (double)lg;
+                    s2 += (double)lg * (double)lg;
+                }
+            }
+            s1 += __shfl_xor(s1, 16, 64);
+            s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 16 && mel < n_mels) {
+                atomicAdd(&st[mel], s1);
+                atomicAdd(&st[n_mels + mel], s2);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// out[b][t][m] <- (x - mean_m) / std_m for t < T_b, 0 for padded rows; masks <- 0; attention mask.
+__global__ __launch_bounds__(256) void kaldi_cmvn_kernel(
+    float* __restrict__ out, const int32_t* __restrict__ lengths, const double* __restrict__ stats,
+    int n_mels, int t_max, int max_frames, int flags, void* __restrict__ attn, int attn_bytes,
+    const int32_t* __restrict__ mask_tbl, int n_masks) {
+    const int clip = blockIdx.y;
+    const int T = kaldi_num_frames(lengths[clip], max_frames, t_max);
+    float* __restrict__ o = out + (size_t)clip * t_max * n_mels;
+    const double* st = stats + (size_t)clip * 2 * n_mels;
+    int m_axis[8], m_s[8], m_e[8];
+    const int nm = mask_tbl ? (n_masks > 8 ? 8 : n_masks) : 0;
+    for (int i = 0; i < nm; ++i) {
+        const int32_t* m = mask_tbl + ((size_t)clip * n_masks + i) * 3;
+        m_axis[i] = m[0];
+        m_s[i] = m[1];
+        m_e[i] = m[2];
+    }
+    const int total = t_max * n_mels;
+    const int stride = gridDim.x * blockDim.x;
+    const double inv_n = T > 0 ? 1.0 / (double)T : 0.0;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int t = e / n_mels, mel = e - t * n_mels;
+        float y = 0.0f;
+        if (t < T) {
+            const double mean = st[mel] * inv_n;
+            double var = st[n_mels + mel] * inv_n - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const float meanf = (float)mean, stdf = (float)sqrt(var);
+            y = (flags & STTFE_KALDI_NO_CMVN) ? o[e] : (o[e] - meanf) / stdf;
+            for (int i = 0; i < nm; ++i) {
+                const int idx = (m_axis[i] == STTFE_AXIS_TIME) ? t : mel;
+                if (idx >= m_s[i] && idx < m_e[i]) y = 0.0f;
+            }
+        }
+        o[e] = y;
+    }
+    if (attn) {
+        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < t_max; t += stride) {
+            if (attn_bytes == 8) reinterpret_cast<int64_t*>(attn)[(size_t)clip * t_max + t] = t < T ? 1 : 0;
+            else reinterpret_cast<int32_t*>(attn)[(size_t)clip * t_max + t] = t < T ? 1 : 0;
+        }
+    }
+}
+
+}  // namespace sttfe
+
+using namespace sttfe;
+
+extern "C" int sttfe_kaldi_workspace_bytes(int batch, int n_mels, size_t* bytes) {
+    if (batch < 0 || n_mels < 1 || n_mels > 128 || !bytes) return STTFE_E_INVALID_ARG;
+    *bytes = ((size_t)batch * 2 * n_mels * sizeof(double) + 255) / 256 * 256;
+    return STTFE_OK;
+}
+
+extern "C" int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, const int32_t* lengths,
+                                      int batch, int n_mels, int t_max, int max_frames, int flags,
+                                      const void* dev_tables, float* out, void* attn_mask, int attn_mask_bytes,
+                                      const int32_t* mask_tbl, int n_masks,
+                                      void* workspace, size_t workspace_bytes, void* stream_) {
+    if (batch < 0 || n_mels < 1 || n_mels > 128 || t_max < 0 || n_masks < 0 || n_masks > 8) return STTFE_E_INVALID_ARG;
+    if (attn_mask && attn_mask_bytes != 4 && attn_mask_bytes != 8) return STTFE_E_INVALID_ARG;
+    if (batch == 0 || t_max == 0) return STTFE_OK;
+    if (!pcm || !offsets || !lengths || !dev_tables || !out || !workspace) return STTFE_E_INVALID_ARG;
+    if (batch > 65535) return STTFE_E_UNSUPPORTED;
+    size_t need = 0;
+    sttfe_kaldi_workspace_bytes(batch, n_mels, &need);
+    if (workspace_bytes < need) return STTFE_E_WORKSPACE;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    double* stats = reinterpret_cast<double*>(workspace);
+    (void)hipGetLastError();
+    if (hip_failed(hipMemsetAsync(stats, 0, need, stream), "hipMemsetAsync(cmvn stats)")) return STTFE_E_LAUNCH;
+    const auto* tab = reinterpret_cast<const KaldiTablesHeader*>(dev_tables);
+    const int n_tiles = (t_max + kaldi::kTileFrames - 1) / kaldi::kTileFrames;
+    const int tiles_per_block = 2;
+    const int bx = (n_tiles + tiles_per_block - 1) / tiles_per_block;
+    {
+        ScopedTiming t(kTimeKaldiFbank, stream);
+        hipLaunchKernelGGL(kaldi_fbank_kernel, dim3(bx, batch), dim3(kaldi::kThreads), 0, stream, pcm, offsets,
+                           lengths, n_mels, t_max, max_frames, tab, out, stats, tiles_per_block);
+    }
+    {
+        ScopedTiming t(kTimeKaldiCmvn, stream);
+        int cx = (t_max * n_mels + 255) / 256;
+        if (cx > 64) cx = 64;
+        hipLaunchKernelGGL(kaldi_cmvn_kernel, dim3(cx, batch), dim3(256), 0, stream, out, lengths, stats, n_mels,
+                           t_max, max_frames, flags, attn_mask, attn_mask_bytes, mask_tbl, n_masks);
+    }
+    if (hip_failed(hipGetLastError(), "kaldi kernel launch")) return STTFE_E_LAUNCH;
+    return STTFE_OK;
+}

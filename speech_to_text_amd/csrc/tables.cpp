@@ -68,7 +68,7 @@ void kaldi_mel_bank(int n_mels, std::vector<float>& dense) {
 
 // Build the banded MFMA plan + A fragments from a dense (n_mels x n_bins) bank times `scale`.
 void build_mel_plan(const std::vector<float>& dense, int n_mels, int n_bins, float scale,
-                    MelPlan& plan, std::vector<float>& afrag) {
+                    int n_waves, int n_ftiles, MelPlan& plan, std::vector<float>& afrag) {
     std::memset(&plan, 0, sizeof(plan));
     plan.n_mels = n_mels;
     plan.n_bins = n_bins;
@@ -105,13 +105,13 @@ void build_mel_plan(const std::vector<float>& dense, int n_mels, int n_bins, flo
     // Longest-processing-time assignment of (mel tile, frame tile) units to the 8 waves.
     struct Unit { int mt, ft, cost; };
     std::vector<Unit> units;
-    for (int ft = 0; ft < kFrameTiles; ++ft)
+    for (int ft = 0; ft < n_ftiles; ++ft)
         for (int mt = 0; mt < plan.n_mtiles; ++mt) units.push_back({mt, ft, plan.nsteps[mt] + 3});
     std::stable_sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.cost > b.cost; });
     int load[kWavesPerBlock] = {0};
     for (const Unit& u : units) {
         int best = 0;
-        for (int w = 1; w < kWavesPerBlock; ++w)
+        for (int w = 1; w < n_waves; ++w)
             if (load[w] < load[best]) best = w;
         // n_mtiles * kFrameTiles = 24 units over 8 waves: LPT never needs more than kMaxUnitsPerWave
         plan.wave_units[best][plan.wave_nunits[best]++] = u.mt | (u.ft << 8);
@@ -139,7 +139,7 @@ static int whisper_tables(int n_mels, std::vector<unsigned char>& blob) {
     std::memset(&h, 0, sizeof(h));
     // 0.25 = the 1/4 of the two-real-frames-in-one-complex-FFT separation, folded into the bank
     // (a power of two: bit-identical to scaling the power spectrum itself).
-    build_mel_plan(dense, n_mels, 201, 0.25f, h.plan, afrag);
+    build_mel_plan(dense, n_mels, 201, 0.25f, kWavesPerBlock, kFrameTiles, h.plan, afrag);
     h.magic = kWhisperMagic;
     h.n_mels = n_mels;
     h.afrag_floats = (int32_t)afrag.size();
@@ -169,6 +169,60 @@ extern "C" int sttfe_whisper_tables_build(int n_mels, void* host_blob, size_t by
     if (!host_blob) return STTFE_E_INVALID_ARG;
     std::vector<unsigned char> blob;
     int rc = whisper_tables(n_mels, blob);
+    if (rc != STTFE_OK) return rc;
+    if (bytes < blob.size()) return STTFE_E_TABLES;
+    std::memcpy(host_blob, blob.data(), blob.size());
+    return STTFE_OK;
+}
+
+// ------------------------------------------------------------------ Kaldi fbank tables --------
+extern "C" int sttfe_kaldi_mel_bank(int n_mels, float* host_dense) {
+    if (n_mels < 1 || n_mels > 128 || !host_dense) return STTFE_E_INVALID_ARG;
+    std::vector<float> dense;
+    kaldi_mel_bank(n_mels, dense);
+    std::memcpy(host_dense, dense.data(), dense.size() * sizeof(float));
+    return STTFE_OK;
+}
+
+static int kaldi_tables(int n_mels, std::vector<unsigned char>& blob) {
+    if (n_mels < 1 || n_mels > 128) return STTFE_E_INVALID_ARG;
+    std::vector<float> dense, afrag;
+    kaldi_mel_bank(n_mels, dense);
+    KaldiTablesHeader h;
+    std::memset(&h, 0, sizeof(h));
+    // 2^28 = (2^15)^2 [the x * 2**15 of HF speech_to_text.py:112 applied to the power spectrum] * 1/4
+    // [two-real-frames separation]; a power of two, so folding it into the bank is exact.
+    build_mel_plan(dense, n_mels, 257, 268435456.0f, 4, 2, h.plan, afrag);
+    h.magic = kKaldiMagic;
+    h.n_mels = n_mels;
+    h.afrag_floats = (int32_t)afrag.size();
+    for (int i = 0; i < 400; ++i)
+        h.window[i] = (float)std::pow(0.5 - 0.5 * std::cos(2.0 * M_PI * i / 399.0), 0.85);
+    for (int k1 = 0; k1 < 16; ++k1)
+        for (int n2 = 0; n2 < 32; ++n2) {
+            const int m = (n2 * k1) % 512;
+            h.twiddle[2 * (32 * k1 + n2)] = (float)std::cos(2.0 * M_PI * m / 512.0);
+            h.twiddle[2 * (32 * k1 + n2) + 1] = (float)(-std::sin(2.0 * M_PI * m / 512.0));
+        }
+    blob.resize(sizeof(h) + afrag.size() * sizeof(float));
+    std::memcpy(blob.data(), &h, sizeof(h));
+    std::memcpy(blob.data() + sizeof(h), afrag.data(), afrag.size() * sizeof(float));
+    return STTFE_OK;
+}
+
+extern "C" int sttfe_kaldi_tables_bytes(int n_mels, size_t* bytes) {
+    if (!bytes) return STTFE_E_INVALID_ARG;
+    std::vector<unsigned char> blob;
+    int rc = kaldi_tables(n_mels, blob);
+    if (rc != STTFE_OK) return rc;
+    *bytes = blob.size();
+    return STTFE_OK;
+}
+
+extern "C" int sttfe_kaldi_tables_build(int n_mels, void* host_blob, size_t bytes) {
+    if (!host_blob) return STTFE_E_INVALID_ARG;
+    std::vector<unsigned char> blob;
+    int rc = kaldi_tables(n_mels, blob);
     if (rc != STTFE_OK) return rc;
     if (bytes < blob.size()) return STTFE_E_TABLES;
     std::memcpy(host_blob, blob.data(), blob.size());

@@ -27,6 +27,17 @@ struct MelPlan {
     int32_t wave_units[kWavesPerBlock][kMaxUnitsPerWave];   // mt | (ft << 8)
 };
 
+struct KaldiTablesHeader {
+    uint32_t magic;
+    int32_t n_mels;
+    int32_t afrag_floats;
+    int32_t reserved;
+    MelPlan plan;               // 4 waves, 2 frame tiles (32-frame workgroup tile)
+    float window[400];          // Povey window, symmetric hanning(400)^0.85
+    float twiddle[1024];        // [k1][n2] complex: W_512^(n2 k1), k1 < 16, n2 < 32
+    // followed by: float afrag[afrag_floats]
+};
+
 struct WhisperTablesHeader {
     uint32_t magic;
     int32_t n_mels;

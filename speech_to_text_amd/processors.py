@@ -237,3 +237,123 @@ class TorchWhisperFeatureExtractor(HipWhisperFeatureExtractor):
             raise NotImplementedError("padding=False (variable-length output) is not implemented by the HIP extractor")
         out = super().__call__(raw_speech, sampling_rate=sampling_rate, return_tensors=return_tensors)
         return SimpleNamespace(input_features=out["input_features"])
+
+
+class HipSpeech2TextFeatureExtractor:
+    """Kaldi fbank + utterance CMVN extractor (HF ``Speech2TextFeatureExtractor`` call shape) on MI355X.
+
+    ``fe(raw_speech, sampling_rate=16000, return_tensors="pt", truncation=True, max_length=N)`` ->
+    ``.input_features`` (B, T, 80) float32 and ``.attention_mask`` (B, T) int32, as used at
+    ``src/data.py:346-358``.  A batch is zero-padded to its longest clip (what the reference's collator
+    does afterwards, ``src/data.py:468-487``).
+    """
+
+    model_input_names = ["input_features", "attention_mask"]
+
+    def __init__(self, feature_size: int = 80, sampling_rate: int = 16000, num_mel_bins: int = 80,
+                 padding_value: float = 0.0, do_ceptral_normalize: bool = True, normalize_means: bool = True,
+                 normalize_vars: bool = True, device: Optional[Union[str, torch.device]] = None, **kwargs):
+        if sampling_rate != 16000:
+            raise ValueError("the HIP kernels implement sampling_rate=16000")
+        if not (do_ceptral_normalize and normalize_means and normalize_vars):
+            raise ValueError("the HIP kernel always applies utterance CMVN (means and variances)")
+        if not 1 <= num_mel_bins <= 128:
+            raise ValueError("num_mel_bins must be in [1, 128]")
+        self.feature_size = feature_size
+        self.num_mel_bins = num_mel_bins
+        self.sampling_rate = sampling_rate
+        self.padding_value = padding_value
+        self.do_ceptral_normalize = True
+        self.normalize_means = True
+        self.normalize_vars = True
+        self.return_attention_mask = True
+        self.n_fft = 512
+        self.hop_length = 160
+        self.win_length = 400
+        self._device_arg = device
+        self._tables = {}
+        self._host_tables = None
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_tables"] = {}
+        return d
+
+    @property
+    def device(self) -> torch.device:
+        return _resolve_device(self._device_arg)
+
+    @property
+    def mel_filters(self) -> np.ndarray:
+        dense = np.empty((self.num_mel_bins, 257), dtype=np.float32)
+        _lib.check(_lib.lib().sttfe_kaldi_mel_bank(self.num_mel_bins, dense.ctypes.data_as(ctypes.c_void_p)))
+        return dense.T.copy()
+
+    @staticmethod
+    def num_frames(n_samples: int, max_length: Optional[int] = None) -> int:
+        t = 1 + (n_samples - 400) // 160 if n_samples >= 400 else 0
+        return min(t, max_length) if max_length else t
+
+    def _tables_on(self, device: torch.device) -> torch.Tensor:
+        t = self._tables.get(device.index)
+        if t is None:
+            if self._host_tables is None:
+                L = _lib.lib()
+                n = ctypes.c_size_t()
+                _lib.check(L.sttfe_kaldi_tables_bytes(self.num_mel_bins, ctypes.byref(n)))
+                host = torch.empty(n.value, dtype=torch.uint8)
+                _lib.check(L.sttfe_kaldi_tables_build(self.num_mel_bins, _lib.ptr(host), n.value))
+                self._host_tables = host
+            t = self._host_tables.to(device)
+            self._tables[device.index] = t
+        return t
+
+    def extract(self, pcm: torch.Tensor, offsets: torch.Tensor, lengths: torch.Tensor, t_max: int,
+                max_frames: int = 0, mask_table: Optional[torch.Tensor] = None,
+                attention_dtype: torch.dtype = torch.int32, apply_cmvn: bool = True):
+        """Device-resident entry -> (features (B, t_max, M) f32, attention_mask (B, t_max))."""
+        device = pcm.device
+        B = int(offsets.shape[0])
+        L = _lib.lib()
+        out = torch.empty((B, t_max, self.num_mel_bins), dtype=torch.float32, device=device)
+        attn = torch.empty((B, t_max), dtype=attention_dtype, device=device)
+        ws_bytes = ctypes.c_size_t()
+        _lib.check(L.sttfe_kaldi_workspace_bytes(B, self.num_mel_bins, ctypes.byref(ws_bytes)))
+        ws = torch.empty(max(ws_bytes.value, 1), dtype=torch.uint8, device=device)
+        n_masks = 0
+        if mask_table is not None:
+            assert mask_table.dtype == torch.int32 and mask_table.dim() == 3 and mask_table.shape[2] == 3
+            mask_table = mask_table.to(device).contiguous()
+            n_masks = int(mask_table.shape[1])
+        stream = torch.cuda.current_stream(device).cuda_stream
+        with torch.cuda.device(device):
+            _lib.check(L.sttfe_kaldi_fbank_cmvn(_lib.ptr(pcm), _lib.ptr(offsets), _lib.ptr(lengths), B,
+                                                self.num_mel_bins, t_max, int(max_frames or 0),
+                                                0 if apply_cmvn else 1,
+                                                _lib.ptr(self._tables_on(device)), _lib.ptr(out), _lib.ptr(attn),
+                                                attn.element_size(), _lib.ptr(mask_table), n_masks,
+                                                _lib.ptr(ws), ws.numel(), ctypes.c_void_p(stream)),
+                       "sttfe_kaldi_fbank_cmvn")
+        return out, attn
+
+    def __call__(self, raw_speech, sampling_rate: Optional[int] = None, return_tensors: Optional[str] = "pt",
+                 padding=True, truncation: bool = False, max_length: Optional[int] = None,
+                 mask_table: Optional[torch.Tensor] = None, **kwargs):
+        if sampling_rate is not None and sampling_rate != self.sampling_rate:
+            raise ValueError(
+                f"The model corresponding to this feature extractor: {self.__class__.__name__} was trained using a "
+                f"sampling rate of {self.sampling_rate}. Please make sure that the provided `raw_speech` input was "
+                f"sampled with {self.sampling_rate} and not {sampling_rate}.")
+        clips = _as_clip_list(raw_speech)
+        device = self.device
+        max_frames = int(max_length) if (truncation and max_length) else 0
+        if not clips:
+            feats = torch.empty((0, 0, self.num_mel_bins), dtype=torch.float32, device=device)
+            attn = torch.empty((0, 0), dtype=torch.int32, device=device)
+        else:
+            pcm, offsets, lengths = pack_clips(clips, device)
+            t_max = max(self.num_frames(int(c.shape[-1]), max_frames or None) for c in clips)
+            feats, attn = self.extract(pcm, offsets, lengths, t_max, max_frames, mask_table)
+        if return_tensors == "np":
+            feats, attn = feats.cpu().numpy(), attn.cpu().numpy()
+        return BatchFeature({"input_features": feats, "attention_mask": attn})

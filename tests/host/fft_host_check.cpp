@@ -37,6 +37,9 @@ static void dft8_wrap(const cf (&in)[8], cf (&out)[8]) {
 int main() {
     srand(1234);
     double e20 = check_small<20>(dft20), e16 = check_small<16>(dft16), e8 = check_small<8>(dft8_wrap);
+    double e32 = check_small<32>(dft32);
+    printf("dft32 %.3e\n", e32);
+    if (e32 > 3e-5) return 1;
     printf("dft20 %.3e dft16 %.3e dft8 %.3e\n", e20, e16, e8);
     if (e20 > 2e-5 || e16 > 2e-5 || e8 > 1e-5) return 1;
 
