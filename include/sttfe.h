@@ -104,6 +104,57 @@ int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, const int32
                            const int32_t* mask_tbl, int n_masks,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------ mono mix, resample, peak normalise, silence trim (rows P1 R P2 P3) ----
+ * Replaces AudioPreprocessor.preprocess, src/data.py:54-108 (same steps in inference.py:100-132):
+ * torch.mean over channels (:66-67), torchaudio.transforms.Resample(orig, 16000) (:70-72),
+ * x / (max|x| + 1e-8) (:78-81), trim to the first..last sample with |x| > threshold * max|x| (:84-91).
+ * The duration gate (:95-98) stays on the host: it only needs the lengths array.
+ *
+ * Plan = the polyphase windowed-sinc kernel of torchaudio's Resample defaults (sinc_interp_hann,
+ * lowpass_filter_width 6, rolloff 0.99) for one (orig_sr, new_sr) pair, built on the HOST; the caller
+ * copies the blob to the device once and passes BOTH copies (the library reads the header from the
+ * host copy, the kernels read the device copy).  Rates are reduced by their gcd; reduced rates above
+ * 1024 return STTFE_E_UNSUPPORTED.
+ */
+int sttfe_resample_plan_bytes(int orig_sr, int new_sr, size_t* bytes);
+int sttfe_resample_plan_build(int orig_sr, int new_sr, void* host_blob, size_t bytes);
+int sttfe_resample_plan_info(const void* host_blob, int* orig_rate, int* new_rate, int* width,
+                             int* n_taps, int* taps_row);
+/* ceil(new * n_in / orig): the output length torchaudio crops to. */
+int sttfe_resample_out_length(int orig_sr, int new_sr, int64_t n_in, int64_t* n_out);
+
+/* Device workspace shared by the two calls below: per-clip peak keys + trim bounds. */
+int sttfe_preprocess_workspace_bytes(int batch, size_t* bytes);
+
+/*
+ * pcm_in       : device float32; clip b = `channels` planar rows of in_lengths[b] samples starting at
+ *                pcm_in[in_offsets[b]] (channels > 1 are averaged to mono).
+ * max_in_length: host upper bound of in_lengths[] (sizes the grid).
+ * dev_plan / host_plan : both NULL = no rate change (mono mix / copy / peak only; pcm_out may alias
+ *                pcm_in when channels == 1).
+ * pcm_out      : device float32; clip b is written at pcm_out[out_offsets[b]], out_lengths[b] =
+ *                ceil(new * in_lengths[b] / orig) samples (out_offsets is chosen by the caller with
+ *                sttfe_resample_out_length; 16-byte aligned starts get the vector-store path).
+ * workspace    : receives max|out| of every clip (consumed by sttfe_normalize_trim).
+ */
+int sttfe_resample_peak(const float* pcm_in, const int64_t* in_offsets, const int32_t* in_lengths,
+                        int batch, int channels, int64_t max_in_length,
+                        const void* dev_plan, const void* host_plan,
+                        float* pcm_out, const int64_t* out_offsets, int32_t* out_lengths,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * In place on the output of sttfe_resample_peak (same workspace, same stream):
+ *   normalize : pcm <- pcm / (peak + 1e-8) for clips with peak > 0 (IEEE float32 division);
+ *   trim      : offsets[b] += first, lengths[b] = last + 1 - first, where first / last are the first and
+ *               last sample with |x| > silence_threshold * max|x| (after normalisation when enabled);
+ *               clips with nothing above the threshold are left unchanged.  No samples move.
+ * max_length : host upper bound of lengths[].
+ */
+int sttfe_normalize_trim(float* pcm, int64_t* offsets, int32_t* lengths, int batch, int64_t max_length,
+                         int normalize, int trim, float silence_threshold,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* Clips per launch pair of sttfe_whisper_logmel (default 96): kernel 1's output for a chunk should
  * still be in the 256 MiB Infinity Cache when the clamp kernel re-reads it.  Tuning knob. */
 int sttfe_set_whisper_chunk(int clips);

@@ -41,9 +41,13 @@ def _declare(lib):
         "sttfe_kaldi_mel_bank": [c_int, p],
         "sttfe_kaldi_workspace_bytes": [c_int, c_int, POINTER(c_size_t)],
         "sttfe_kaldi_fbank_cmvn": [p, p, p, c_int, c_int, c_int, c_int, c_int, p, p, p, c_int, p, c_int, p, c_size_t, p],
-        "sttfe_resample_taps": [c_int, c_int, p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)],
-        "sttfe_resample_peak": [p, p, p, c_int, c_int, c_int, p, c_int, p, p, p, p, p],
-        "sttfe_normalize_trim": [p, p, p, c_int, c_int, c_int, c_float, p, p, p, p],
+        "sttfe_resample_plan_bytes": [c_int, c_int, POINTER(c_size_t)],
+        "sttfe_resample_plan_build": [c_int, c_int, p, c_size_t],
+        "sttfe_resample_plan_info": [p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)],
+        "sttfe_resample_out_length": [c_int, c_int, c_int64, POINTER(c_int64)],
+        "sttfe_preprocess_workspace_bytes": [c_int, POINTER(c_size_t)],
+        "sttfe_resample_peak": [p, p, p, c_int, c_int, c_int64, p, p, p, p, p, p, c_size_t, p],
+        "sttfe_normalize_trim": [p, p, p, c_int, c_int64, c_int, c_int, c_float, p, c_size_t, p],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name, None)

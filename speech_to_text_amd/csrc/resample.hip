@@ -1,0 +1,327 @@
+// Waveform preprocessing for gfx950 (MI355X): mono mix, polyphase windowed-sinc resampling, per-clip
+// peak, peak normalisation and silence trim.
+//
+// Replaces AudioPreprocessor.preprocess (reference src/data.py:54-108; same steps in
+// inference.py:100-132): torch.mean over channels (:66-67), torchaudio.transforms.Resample (:70-72),
+// x / (max|x| + 1e-8) (:78-81), trim to the first..last sample above 0.01 * max (:84-91).
+//
+// Kernel 1a (decimate_peak<ORIG>): integer decimation ORIG:1 (48 -> 16 kHz: ORIG = 3, 41 taps;
+//   32 -> 16 kHz: ORIG = 2, 28 taps).  One 256-thread workgroup per 1024-output tile: the input span
+//   is read from HBM once with lane-contiguous loads and de-interleaved into ORIG phase rows in LDS
+//   (row r holds padded[ORIG m + r]), so that out[i] = sum_r sum_j h[ORIG j + r] * row_r[i + j] and a
+//   thread that owns 4 consecutive outputs reads each row with five conflict-free ds_read_b128
+//   (17 of 20 values used) instead of 41 scalar reads per output.  Taps are wave-uniform (SGPRs).
+//   Output: one global_store_dwordx4 per thread; per-clip max|out| with one atomicMax per wave.
+// Kernel 1b (resample_generic): any ORIG:NEW ratio, one thread per output sample over the non-zero
+//   span of its phase's taps (44.1 kHz etc.; correct, not tuned).
+// Kernel 1c (copy_peak): same-rate input: mono mix / copy / peak only.
+// Kernel 2 (normalize_trim): y = x / (peak + 1e-8) in place (IEEE division, bit-identical to the
+//   float32 NumPy / torch result) and first / last index with |y| > thr via atomicMin / atomicMax.
+// Kernel 3 (trim_finalize): offsets[b] += first, lengths[b] = last + 1 - first.  Trimming moves no
+//   samples: every later kernel addresses a clip through the device offsets / lengths arrays.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sttfe.h"
+#include "tables.h"
+#include "timing.h"
+
+namespace sttfe {
+
+namespace rs {
+constexpr int kThreads = 256;
+constexpr int kOutPerThread = 4;
+constexpr int kTile = kThreads * kOutPerThread;       // 1024 outputs per tile
+constexpr int kTapsPerPhase = 14;                     // ceil((2 width + ORIG) / ORIG) for every ORIG:1 ratio
+constexpr int kRowLen = kTile + 16;                   // m range a tile reads: 4 * 255 + 20
+constexpr int kRowStride = 1068;                      // words; % 4 == 0 (b128 alignment), % 32 == 12
+static_assert(kRowStride >= kRowLen && kRowStride % 4 == 0, "phase row stride");
+}  // namespace rs
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// Sample i of the mono mix of a (channels, n) planar clip (src/data.py:66-67: torch.mean(dim=0)).
+__device__ __forceinline__ float mono_at(const float* __restrict__ x, int n, int channels, int i) {
+    if (channels == 1) return x[i];
+    float s = 0.f;
+    for (int c = 0; c < channels; ++c) s += x[(size_t)c * n + i];
+    return s / (float)channels;
+}
+
+template <int ORIG>
+__global__ __launch_bounds__(rs::kThreads) void decimate_peak_kernel(
+    const float* __restrict__ pcm_in, const int64_t* __restrict__ in_off, const int32_t* __restrict__ in_len,
+    int channels, const ResamplePlanHeader* __restrict__ plan, float* __restrict__ pcm_out,
+    const int64_t* __restrict__ out_off, int32_t* __restrict__ out_len, unsigned* __restrict__ peak_keys,
+    int tiles_per_block) {
+    using namespace rs;
+    __shared__ __attribute__((aligned(16))) float rows[ORIG * kRowStride];
+    const int clip = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int n = in_len[clip];
+    const int n_out = (n + ORIG - 1) / ORIG;                       // ceil(1 * n / ORIG)
+    if (blockIdx.x == 0 && tid == 0) out_len[clip] = n_out;
+    const int n_tiles = (n_out + kTile - 1) / kTile;
+    const int tile_begin = blockIdx.x * tiles_per_block;
+    const int tile_end = min(tile_begin + tiles_per_block, n_tiles);
+    if (tile_begin >= tile_end) return;
+    const float* __restrict__ x = pcm_in + in_off[clip];
+    float* __restrict__ y = pcm_out + out_off[clip];
+    const float* __restrict__ h = reinterpret_cast<const float*>(plan + 1) + 2 * plan->new_rate;   // taps of phase 0
+    const int width = plan->width;
+    float peak = 0.f;
+
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        const int o0 = tile * kTile;
+        __syncthreads();                                            // previous tile's row reads are done
+        // padded[ORIG * o0 + g] = x[ORIG * o0 + g - width] (zero outside the clip) -> rows[g % ORIG][g / ORIG]
+        for (int g = tid; g < ORIG * kRowLen; g += kThreads) {
+            const int src = ORIG * o0 + g - width;
+            const float v = (src >= 0 && src < n) ? mono_at(x, n, channels, src) : 0.f;
+            rows[(g % ORIG) * kRowStride + g / ORIG] = v;
+        }
+        __syncthreads();
+        float acc[kOutPerThread] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < ORIG; ++r) {
+            float v[20];
+            const f32x4* src = reinterpret_cast<const f32x4*>(rows + r * kRowStride + kOutPerThread * tid);
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                const f32x4 q = src[c];
+                v[4 * c] = q.x; v[4 * c + 1] = q.y; v[4 * c + 2] = q.z; v[4 * c + 3] = q.w;
+            }
+#pragma unroll
+            for (int j = 0; j < kTapsPerPhase; ++j) {
+                const float hj = h[ORIG * j + r];                   // wave-uniform (scalar load)
+#pragma unroll
+                for (int q = 0; q < kOutPerThread; ++q) acc[q] = fmaf(hj, v[q + j], acc[q]);
+            }
+        }
+        const int o = o0 + kOutPerThread * tid;
+        if (o + kOutPerThread <= n_out && ((reinterpret_cast<uintptr_t>(y + o) & 15) == 0)) {
+            *reinterpret_cast<f32x4*>(y + o) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+#pragma unroll
+            for (int q = 0; q < kOutPerThread; ++q) peak = fmaxf(peak, fabsf(acc[q]));
+        } else {
+#pragma unroll
+            for (int q = 0; q < kOutPerThread; ++q)
+                if (o + q < n_out) {
+                    y[o + q] = acc[q];
+                    peak = fmaxf(peak, fabsf(acc[q]));
+                }
+        }
+    }
+    peak = wave_max(peak);
+    if ((tid & 63) == 0) atomicMax(&peak_keys[clip], __float_as_uint(peak));    // peak >= 0: bit order == value order
+}
+
+__global__ __launch_bounds__(256) void resample_generic_kernel(
+    const float* __restrict__ pcm_in, const int64_t* __restrict__ in_off, const int32_t* __restrict__ in_len,
+    int channels, const ResamplePlanHeader* __restrict__ plan, float* __restrict__ pcm_out,
+    const int64_t* __restrict__ out_off, int32_t* __restrict__ out_len, unsigned* __restrict__ peak_keys) {
+    const int clip = blockIdx.y;
+    const int n = in_len[clip];
+    const int orig = plan->orig_rate, nw = plan->new_rate, width = plan->width, row = plan->taps_row;
+    const int n_out = (int)(((int64_t)nw * n + orig - 1) / orig);
+    if (blockIdx.x == 0 && threadIdx.x == 0) out_len[clip] = n_out;
+    const int32_t* __restrict__ lo = reinterpret_cast<const int32_t*>(plan + 1);
+    const int32_t* __restrict__ hi = lo + nw;
+    const float* __restrict__ taps = reinterpret_cast<const float*>(hi + nw);
+    const float* __restrict__ x = pcm_in + in_off[clip];
+    float* __restrict__ y = pcm_out + out_off[clip];
+    float peak = 0.f;
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += gridDim.x * blockDim.x) {
+        const int i = o / nw, p = o - i * nw;
+        const int base = i * orig - width;
+        const float* __restrict__ hp = taps + (size_t)p * row;
+        int k0 = lo[p], k1 = hi[p];
+        k0 = max(k0, -base);
+        k1 = min(k1, n - base);
+        float acc = 0.f;
+        for (int k = k0; k < k1; ++k) acc = fmaf(hp[k], mono_at(x, n, channels, base + k), acc);
+        y[o] = acc;
+        peak = fmaxf(peak, fabsf(acc));
+    }
+    peak = wave_max(peak);
+    if ((threadIdx.x & 63) == 0) atomicMax(&peak_keys[clip], __float_as_uint(peak));
+}
+
+// Same-rate path: optional mono mix / copy, and the per-clip peak.
+__global__ __launch_bounds__(256) void copy_peak_kernel(
+    const float* __restrict__ pcm_in, const int64_t* __restrict__ in_off, const int32_t* __restrict__ in_len,
+    int channels, float* __restrict__ pcm_out, const int64_t* __restrict__ out_off, int32_t* __restrict__ out_len,
+    unsigned* __restrict__ peak_keys) {
+    const int clip = blockIdx.y;
+    const int n = in_len[clip];
+    if (blockIdx.x == 0 && threadIdx.x == 0) out_len[clip] = n;
+    const float* __restrict__ x = pcm_in + in_off[clip];
+    float* __restrict__ y = pcm_out + out_off[clip];
+    const bool store = (y != x) || channels != 1;
+    float peak = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float v = mono_at(x, n, channels, i);
+        if (store) y[i] = v;
+        peak = fmaxf(peak, fabsf(v));
+    }
+    peak = wave_max(peak);
+    if ((threadIdx.x & 63) == 0) atomicMax(&peak_keys[clip], __float_as_uint(peak));
+}
+
+__global__ __launch_bounds__(256) void normalize_trim_kernel(
+    float* __restrict__ pcm, const int64_t* __restrict__ offsets, const int32_t* __restrict__ lengths,
+    const unsigned* __restrict__ peak_keys, int normalize, int trim, float thr_factor,
+    int* __restrict__ first, int* __restrict__ last) {
+    const int clip = blockIdx.y;
+    const int n = lengths[clip];
+    const float peak = __uint_as_float(peak_keys[clip]);
+    if (!(peak > 0.f)) return;                  // src/data.py:80 `if max_abs > 0`; nothing is above 0 * thr either
+    float* __restrict__ x = pcm + offsets[clip];
+    const float d = peak + 1e-8f;               // src/data.py:81 (float32 tensor + python scalar -> float32)
+    const float top = normalize ? __fdiv_rn(peak, d) : peak;      // max|y|: division is monotonic
+    const float thr = top * thr_factor;         // src/data.py:86
+    int lo = 0x7fffffff, hi = -1;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float v = x[i];
+        if (normalize) {
+            v = __fdiv_rn(v, d);
+            x[i] = v;
+        }
+        if (trim && fabsf(v) > thr) {
+            lo = min(lo, i);
+            hi = max(hi, i);
+        }
+    }
+    if (trim) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = min(lo, __shfl_xor(lo, off, 64));
+            hi = max(hi, __shfl_xor(hi, off, 64));
+        }
+        if ((threadIdx.x & 63) == 0 && hi >= 0) {
+            atomicMin(&first[clip], lo);
+            atomicMax(&last[clip], hi);
+        }
+    }
+}
+
+__global__ void trim_finalize_kernel(int64_t* __restrict__ offsets, int32_t* __restrict__ lengths,
+                                     const int* __restrict__ first, const int* __restrict__ last, int batch) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const int f = first[b], l = last[b];
+    if (l >= f && l >= 0) {                     // src/data.py:87 `if mask.any()`
+        offsets[b] += f;
+        lengths[b] = l + 1 - f;
+    }
+}
+
+}  // namespace sttfe
+
+using namespace sttfe;
+
+// workspace layout: [peak keys u32 x B][first i32 x B][last i32 x B], 256-byte aligned total
+extern "C" int sttfe_preprocess_workspace_bytes(int batch, size_t* bytes) {
+    if (batch < 0 || !bytes) return STTFE_E_INVALID_ARG;
+    *bytes = ((size_t)batch * 3 * sizeof(int32_t) + 255) / 256 * 256;
+    return STTFE_OK;
+}
+
+extern "C" int sttfe_resample_peak(const float* pcm_in, const int64_t* in_offsets, const int32_t* in_lengths,
+                                   int batch, int channels, int64_t max_in_length,
+                                   const void* dev_plan, const void* host_plan,
+                                   float* pcm_out, const int64_t* out_offsets, int32_t* out_lengths,
+                                   void* workspace, size_t workspace_bytes, void* stream_) {
+    if (batch < 0 || channels < 1 || channels > 64 || max_in_length < 0) return STTFE_E_INVALID_ARG;
+    if (batch == 0) return STTFE_OK;
+    if (!pcm_in || !in_offsets || !in_lengths || !pcm_out || !out_offsets || !out_lengths || !workspace)
+        return STTFE_E_INVALID_ARG;
+    if ((dev_plan == nullptr) != (host_plan == nullptr)) return STTFE_E_INVALID_ARG;
+    if (batch > 65535) return STTFE_E_UNSUPPORTED;
+    size_t need = 0;
+    sttfe_preprocess_workspace_bytes(batch, &need);
+    if (workspace_bytes < need) return STTFE_E_WORKSPACE;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    unsigned* keys = reinterpret_cast<unsigned*>(workspace);
+    (void)hipGetLastError();
+    if (hip_failed(hipMemsetAsync(keys, 0, (size_t)batch * sizeof(unsigned), stream), "hipMemsetAsync(peak keys)"))
+        return STTFE_E_LAUNCH;
+    ScopedTiming t(kTimeResample, stream);
+    if (!dev_plan) {
+        int bx = (int)((max_in_length + 256 * 8 - 1) / (256 * 8));
+        bx = bx < 1 ? 1 : (bx > 1024 ? 1024 : bx);
+        hipLaunchKernelGGL(copy_peak_kernel, dim3(bx, batch), dim3(256), 0, stream, pcm_in, in_offsets, in_lengths,
+                           channels, pcm_out, out_offsets, out_lengths, keys);
+    } else {
+        const auto* hp = reinterpret_cast<const ResamplePlanHeader*>(host_plan);
+        if (hp->magic != kResampleMagic) return STTFE_E_TABLES;
+        const auto* dp = reinterpret_cast<const ResamplePlanHeader*>(dev_plan);
+        const int64_t max_out = (hp->new_rate * max_in_length + hp->orig_rate - 1) / hp->orig_rate;
+        const bool fast = hp->new_rate == 1 && hp->taps_row <= rs::kTapsPerPhase * hp->orig_rate &&
+                          (hp->orig_rate == 2 || hp->orig_rate == 3 || hp->orig_rate == 4 || hp->orig_rate == 6);
+        if (fast) {
+            const int tiles_per_block = 4;
+            const int64_t n_tiles = (max_out + rs::kTile - 1) / rs::kTile;
+            int bx = (int)((n_tiles + tiles_per_block - 1) / tiles_per_block);
+            bx = bx < 1 ? 1 : bx;
+            const dim3 grid(bx, batch), block(rs::kThreads);
+#define STTFE_LAUNCH_DECIMATE(O)                                                                             \
+    hipLaunchKernelGGL(decimate_peak_kernel<O>, grid, block, 0, stream, pcm_in, in_offsets, in_lengths,      \
+                       channels, dp, pcm_out, out_offsets, out_lengths, keys, tiles_per_block)
+            switch (hp->orig_rate) {
+                case 2: STTFE_LAUNCH_DECIMATE(2); break;
+                case 3: STTFE_LAUNCH_DECIMATE(3); break;
+                case 4: STTFE_LAUNCH_DECIMATE(4); break;
+                default: STTFE_LAUNCH_DECIMATE(6); break;
+            }
+#undef STTFE_LAUNCH_DECIMATE
+        } else {
+            int bx = (int)((max_out + 256 * 4 - 1) / (256 * 4));
+            bx = bx < 1 ? 1 : (bx > 2048 ? 2048 : bx);
+            hipLaunchKernelGGL(resample_generic_kernel, dim3(bx, batch), dim3(256), 0, stream, pcm_in, in_offsets,
+                               in_lengths, channels, dp, pcm_out, out_offsets, out_lengths, keys);
+        }
+    }
+    if (hip_failed(hipGetLastError(), "resample kernel launch")) return STTFE_E_LAUNCH;
+    return STTFE_OK;
+}
+
+extern "C" int sttfe_normalize_trim(float* pcm, int64_t* offsets, int32_t* lengths, int batch,
+                                    int64_t max_length, int normalize, int trim, float silence_threshold,
+                                    void* workspace, size_t workspace_bytes, void* stream_) {
+    if (batch < 0 || max_length < 0) return STTFE_E_INVALID_ARG;
+    if (batch == 0 || (!normalize && !trim)) return STTFE_OK;
+    if (!pcm || !offsets || !lengths || !workspace) return STTFE_E_INVALID_ARG;
+    if (batch > 65535) return STTFE_E_UNSUPPORTED;
+    size_t need = 0;
+    sttfe_preprocess_workspace_bytes(batch, &need);
+    if (workspace_bytes < need) return STTFE_E_WORKSPACE;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    unsigned* keys = reinterpret_cast<unsigned*>(workspace);
+    int* first = reinterpret_cast<int*>(keys + batch);
+    int* last = first + batch;
+    (void)hipGetLastError();
+    if (trim) {
+        if (hip_failed(hipMemsetAsync(first, 0x7f, (size_t)batch * sizeof(int), stream), "hipMemsetAsync(first)") ||
+            hip_failed(hipMemsetAsync(last, 0xff, (size_t)batch * sizeof(int), stream), "hipMemsetAsync(last)"))
+            return STTFE_E_LAUNCH;
+    }
+    {
+        ScopedTiming t(kTimeNormTrim, stream);
+        int bx = (int)((max_length + 256 * 8 - 1) / (256 * 8));
+        bx = bx < 1 ? 1 : (bx > 1024 ? 1024 : bx);
+        hipLaunchKernelGGL(normalize_trim_kernel, dim3(bx, batch), dim3(256), 0, stream, pcm, offsets, lengths, keys,
+                           normalize, trim, silence_threshold, first, last);
+        if (trim)
+            hipLaunchKernelGGL(trim_finalize_kernel, dim3((batch + 255) / 256), dim3(256), 0, stream, offsets, lengths,
+                               first, last, batch);
+    }
+    if (hip_failed(hipGetLastError(), "normalize/trim kernel launch")) return STTFE_E_LAUNCH;
+    return STTFE_OK;
+}

@@ -228,3 +228,105 @@ extern "C" int sttfe_kaldi_tables_build(int n_mels, void* host_blob, size_t byte
     std::memcpy(host_blob, blob.data(), blob.size());
     return STTFE_OK;
 }
+
+// ------------------------------------------------------------------ resampler plan ------------
+// torchaudio.functional._get_sinc_resample_kernel with the transform's defaults (sinc_interp_hann,
+// lowpass_filter_width 6, rolloff 0.99, kernel built in float64 and cast to float32), as restated in
+// SURVEY.md section 8a row R.  The reference calls it through torchaudio.transforms.Resample
+// (src/data.py:70-72, inference.py:111-113).
+static int resample_plan(int orig_sr, int new_sr, std::vector<unsigned char>& blob) {
+    if (orig_sr < 1 || new_sr < 1) return STTFE_E_INVALID_ARG;
+    int a = orig_sr, b = new_sr;
+    while (b) { const int t = a % b; a = b; b = t; }
+    const int orig = orig_sr / a, nw = new_sr / a;
+    if (orig > 1024 || nw > 1024) return STTFE_E_UNSUPPORTED;
+    const double lowpass_width = 6.0, rolloff = 0.99;
+    const double base = (double)std::min(orig, nw) * rolloff;
+    const int width = (int)std::ceil(lowpass_width * orig / base);
+    const int n_taps = 2 * width + orig;
+    const int row = (n_taps + orig - 1) / orig * orig;
+    ResamplePlanHeader h;
+    std::memset(&h, 0, sizeof(h));
+    h.magic = kResampleMagic;
+    h.orig_rate = orig;
+    h.new_rate = nw;
+    h.width = width;
+    h.n_taps = n_taps;
+    h.taps_row = row;
+    std::vector<int32_t> lo(nw), hi(nw);
+    std::vector<float> taps((size_t)nw * row, 0.0f);
+    const double scale = base / orig;
+    for (int p = 0; p < nw; ++p) {
+        // torch: arange(0, -new, -1) / new is a float32 division, promoted to float64 by the add
+        const double phase = (double)((float)(-p) / (float)nw);
+        int l = n_taps, r = 0;
+        for (int k = 0; k < n_taps; ++k) {
+            double t = (phase + (double)(k - width) / (double)orig) * base;
+            t = std::max(-lowpass_width, std::min(lowpass_width, t));
+            const double c = std::cos(t * M_PI / lowpass_width / 2.0);
+            const double window = c * c;
+            t *= M_PI;
+            const double sinc = (t == 0.0) ? 1.0 : std::sin(t) / t;
+            const float v = (float)(sinc * window * scale);
+            taps[(size_t)p * row + k] = v;
+            if (v != 0.0f) {
+                l = std::min(l, k);
+                r = std::max(r, k + 1);
+            }
+        }
+        lo[p] = std::min(l, r);
+        hi[p] = r;
+    }
+    blob.resize(sizeof(h) + 2 * (size_t)nw * sizeof(int32_t) + taps.size() * sizeof(float));
+    unsigned char* q = blob.data();
+    std::memcpy(q, &h, sizeof(h));
+    q += sizeof(h);
+    std::memcpy(q, lo.data(), (size_t)nw * sizeof(int32_t));
+    q += (size_t)nw * sizeof(int32_t);
+    std::memcpy(q, hi.data(), (size_t)nw * sizeof(int32_t));
+    q += (size_t)nw * sizeof(int32_t);
+    std::memcpy(q, taps.data(), taps.size() * sizeof(float));
+    return STTFE_OK;
+}
+
+extern "C" int sttfe_resample_plan_bytes(int orig_sr, int new_sr, size_t* bytes) {
+    if (!bytes) return STTFE_E_INVALID_ARG;
+    std::vector<unsigned char> blob;
+    int rc = resample_plan(orig_sr, new_sr, blob);
+    if (rc != STTFE_OK) return rc;
+    *bytes = blob.size();
+    return STTFE_OK;
+}
+
+extern "C" int sttfe_resample_plan_build(int orig_sr, int new_sr, void* host_blob, size_t bytes) {
+    if (!host_blob) return STTFE_E_INVALID_ARG;
+    std::vector<unsigned char> blob;
+    int rc = resample_plan(orig_sr, new_sr, blob);
+    if (rc != STTFE_OK) return rc;
+    if (bytes < blob.size()) return STTFE_E_TABLES;
+    std::memcpy(host_blob, blob.data(), blob.size());
+    return STTFE_OK;
+}
+
+// Geometry + float32 taps of the plan (for inspection / tests): taps_out may be NULL.
+extern "C" int sttfe_resample_plan_info(const void* host_blob, int* orig_rate, int* new_rate, int* width,
+                                        int* n_taps, int* taps_row) {
+    if (!host_blob) return STTFE_E_INVALID_ARG;
+    const auto* h = reinterpret_cast<const ResamplePlanHeader*>(host_blob);
+    if (h->magic != kResampleMagic) return STTFE_E_TABLES;
+    if (orig_rate) *orig_rate = h->orig_rate;
+    if (new_rate) *new_rate = h->new_rate;
+    if (width) *width = h->width;
+    if (n_taps) *n_taps = h->n_taps;
+    if (taps_row) *taps_row = h->taps_row;
+    return STTFE_OK;
+}
+
+extern "C" int sttfe_resample_out_length(int orig_sr, int new_sr, int64_t n_in, int64_t* n_out) {
+    if (orig_sr < 1 || new_sr < 1 || n_in < 0 || !n_out) return STTFE_E_INVALID_ARG;
+    int a = orig_sr, b = new_sr;
+    while (b) { const int t = a % b; a = b; b = t; }
+    const int64_t orig = orig_sr / a, nw = new_sr / a;
+    *n_out = (nw * n_in + orig - 1) / orig;          // ceil(new * n / orig)
+    return STTFE_OK;
+}

@@ -11,6 +11,7 @@ constexpr int kFrameTiles = 3;           // 48 frames per block iteration / 16 c
 
 constexpr uint32_t kWhisperMagic = 0x57484d31u;   // "WHM1"
 constexpr uint32_t kKaldiMagic = 0x4b414c31u;     // "KAL1"
+constexpr uint32_t kResampleMagic = 0x52534d31u;  // "RSM1"
 
 // Banded mel projection on 16x16x4 f32 MFMA tiles.  Mel tile mt covers mel rows [16 mt, 16 mt + 16)
 // and FFT bins [kstart, kstart + 4 nsteps).  afrag holds, for step s and lane l, the A operand
@@ -47,6 +48,20 @@ struct WhisperTablesHeader {
     float window[400];          // periodic Hann
     float twiddle[800];         // [k1][j] complex: W_400^(j k1) = (cos, -sin)(2 pi j k1 / 400)
     // followed by: float afrag[afrag_floats]
+};
+
+// Polyphase windowed-sinc resampler (torchaudio.transforms.Resample defaults).  Output sample
+// i * new_rate + p = sum_k taps[p][k] * padded[i * orig_rate + k], padded = input with `width` zeros in front.
+struct ResamplePlanHeader {
+    uint32_t magic;
+    int32_t orig_rate;          // rates divided by their gcd
+    int32_t new_rate;
+    int32_t width;
+    int32_t n_taps;             // 2 width + orig_rate
+    int32_t taps_row;           // floats per phase row: n_taps rounded up to a multiple of orig_rate (zero filled)
+    int32_t reserved[2];
+    // followed by: int32 lo[new_rate], int32 hi[new_rate] (non-zero tap span [lo, hi) of each phase),
+    //              float taps[new_rate][taps_row]
 };
 
 }  // namespace sttfe

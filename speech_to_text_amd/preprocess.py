@@ -1,0 +1,230 @@
+"""Batched waveform preprocessing on the GPU: mono mix, resample, peak normalise, silence trim, gate.
+
+Device-side counterpart of ``AudioPreprocessor`` (reference ``src/data.py:42-116``; the same steps are
+repeated in ``inference.py:100-132``).  The reference runs these per clip on the CPU inside DataLoader
+workers; here a whole batch of decoded PCM goes through ``sttfe_resample_peak`` +
+``sttfe_normalize_trim`` (``include/sttfe.h``) and stays in HBM, addressed by device
+``offsets`` / ``lengths`` arrays that the feature kernels consume directly (trimming moves no samples).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .processors import _resolve_device
+
+_ALIGN = 64          # samples; keeps every clip start 256-byte aligned
+
+
+@dataclass
+class PackedAudio:
+    """A batch of mono clips in one device buffer."""
+    pcm: torch.Tensor            # float32 (total,)
+    offsets: torch.Tensor        # int64 (B,) device: clip b starts at pcm[offsets[b]]
+    lengths: torch.Tensor        # int32 (B,) device
+    host_lengths: List[int]      # the same lengths on the host
+    sample_rate: int
+    keep: List[bool]             # duration gate (src/data.py:95-98); False = the reference returns None
+
+    @property
+    def durations(self) -> List[float]:
+        return [n / self.sample_rate for n in self.host_lengths]
+
+    def clip(self, b: int) -> torch.Tensor:
+        """Clip b as a (1, n) tensor view (the shape ``preprocess`` returns in the reference)."""
+        o = int(self.offsets[b].item())
+        return self.pcm[o:o + self.host_lengths[b]].unsqueeze(0)
+
+
+class ResamplePlan:
+    """Host + device copies of one (orig_sr, new_sr) polyphase kernel (torchaudio Resample defaults)."""
+
+    def __init__(self, orig_sr: int, new_sr: int):
+        L = _lib.lib()
+        n = ctypes.c_size_t()
+        _lib.check(L.sttfe_resample_plan_bytes(int(orig_sr), int(new_sr), ctypes.byref(n)), "sttfe_resample_plan_bytes")
+        self.host = torch.empty(n.value, dtype=torch.uint8)
+        _lib.check(L.sttfe_resample_plan_build(int(orig_sr), int(new_sr), _lib.ptr(self.host), n.value))
+        vals = [ctypes.c_int() for _ in range(5)]
+        _lib.check(L.sttfe_resample_plan_info(_lib.ptr(self.host), *[ctypes.byref(v) for v in vals]))
+        self.orig, self.new, self.width, self.n_taps, self.taps_row = [v.value for v in vals]
+        self._dev: Dict[int, torch.Tensor] = {}
+
+    def on(self, device: torch.device) -> torch.Tensor:
+        t = self._dev.get(device.index)
+        if t is None:
+            t = self.host.to(device)
+            self._dev[device.index] = t
+        return t
+
+    def out_length(self, n_in: int) -> int:
+        return (self.new * n_in + self.orig - 1) // self.orig
+
+    @property
+    def taps(self) -> np.ndarray:
+        """(new, n_taps) float32 kernel, same layout as torchaudio's (new, 1, n_taps) squeezed."""
+        off = 32 + 8 * self.new
+        rows = self.host[off:].numpy().view(np.float32).reshape(self.new, self.taps_row)
+        return rows[:, :self.n_taps].copy()
+
+
+def pack_planar(clips: Sequence, device: torch.device):
+    """Clips of identical channel count -> (pcm, offsets int64, lengths int32, host lengths, channels).
+
+    Clip b is stored as ``channels`` planar rows of ``lengths[b]`` samples (what
+    ``sttfe_resample_peak`` expects).  Host arrays go through one pinned staging buffer.
+    """
+    arrs, lens, chans = [], [], None
+    for c in clips:
+        if torch.is_tensor(c):
+            a = c.detach()
+            a = a.reshape(1, -1) if a.dim() == 1 else a.reshape(a.shape[0], -1)
+            a = a.to(torch.float32)
+        else:
+            a = np.asarray(c, dtype=np.float32)
+            a = a.reshape(1, -1) if a.ndim == 1 else a.reshape(a.shape[0], -1)
+        if chans is None:
+            chans = int(a.shape[0])
+        elif chans != int(a.shape[0]):
+            raise ValueError("pack_planar: all clips of one call must have the same channel count")
+        arrs.append(a)
+        lens.append(int(a.shape[1]))
+    starts, total = [], 0
+    for n in lens:
+        starts.append(total)
+        total += (chans * n + _ALIGN - 1) // _ALIGN * _ALIGN
+    pcm = torch.empty(total + _ALIGN, dtype=torch.float32, device=device)
+    host_idx = [i for i, a in enumerate(arrs) if not torch.is_tensor(a) or not a.is_cuda]
+    if host_idx:
+        stage = torch.empty(total + _ALIGN, dtype=torch.float32, pin_memory=torch.cuda.is_available())
+        sn = stage.numpy()
+        for i in host_idx:
+            a = arrs[i].numpy() if torch.is_tensor(arrs[i]) else arrs[i]
+            sn[starts[i]:starts[i] + chans * lens[i]] = a.reshape(-1)
+        if len(host_idx) == len(arrs):
+            pcm.copy_(stage, non_blocking=True)
+        else:
+            for i in host_idx:
+                s, e = starts[i], starts[i] + chans * lens[i]
+                pcm[s:e].copy_(stage[s:e], non_blocking=True)
+    for i, a in enumerate(arrs):
+        if torch.is_tensor(a) and a.is_cuda:
+            pcm[starts[i]:starts[i] + chans * lens[i]].copy_(a.reshape(-1))
+    offsets = torch.tensor(starts, dtype=torch.int64).to(device, non_blocking=True)
+    lengths = torch.tensor(lens, dtype=torch.int32).to(device, non_blocking=True)
+    return pcm, offsets, lengths, lens, chans
+
+
+class GpuAudioPreprocessor:
+    """``AudioPreprocessor`` (src/data.py:42-116) for whole batches, on the GPU.
+
+    ``config`` is the reference's project config (``config.data.sample_rate`` ...), a ``DataConfig``,
+    or None with keyword overrides.
+    """
+
+    def __init__(self, config: Any = None, *, device: Optional[Union[str, torch.device]] = None, **overrides):
+        data = getattr(config, "data", config)
+        get = lambda k, d: overrides.get(k, getattr(data, k, d) if data is not None else d)
+        self.sample_rate = int(get("sample_rate", 16000))
+        self.min_duration = float(get("min_duration", 0.5))
+        self.max_duration = float(get("max_duration", 30.0))
+        self.normalize = bool(get("normalize", True))
+        self.trim_silence = bool(get("trim_silence", True))
+        self.silence_threshold = float(get("silence_threshold", 0.01))
+        self._device_arg = device
+        self._plans: Dict[int, ResamplePlan] = {}
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_plans"] = {}
+        return d
+
+    @property
+    def device(self) -> torch.device:
+        return _resolve_device(self._device_arg)
+
+    def plan(self, original_sample_rate: int) -> Optional[ResamplePlan]:
+        if int(original_sample_rate) == self.sample_rate:
+            return None
+        p = self._plans.get(int(original_sample_rate))
+        if p is None:
+            p = ResamplePlan(int(original_sample_rate), self.sample_rate)
+            self._plans[int(original_sample_rate)] = p
+        return p
+
+    def run(self, pcm_in: torch.Tensor, in_offsets: torch.Tensor, in_lengths: torch.Tensor,
+            host_lengths: Sequence[int], channels: int, original_sample_rate: int,
+            sync_lengths: Optional[bool] = None) -> PackedAudio:
+        """Device-resident entry: packed (planar) PCM at ``original_sample_rate`` -> PackedAudio at 16 kHz.
+
+        ``sync_lengths`` (default: only when trimming) copies the trimmed lengths back to the host,
+        which is what the duration gate and Speech2Text's dynamic padding need.
+        """
+        device = pcm_in.device
+        L = _lib.lib()
+        B = len(host_lengths)
+        plan = self.plan(original_sample_rate)
+        out_lens = [plan.out_length(n) if plan else int(n) for n in host_lengths]
+        starts, total = [], 0
+        for n in out_lens:
+            starts.append(total)
+            total += (n + _ALIGN - 1) // _ALIGN * _ALIGN
+        alias = plan is None and channels == 1
+        if alias:
+            pcm_out, out_offsets = pcm_in, in_offsets.clone()
+        else:
+            pcm_out = torch.empty(total + _ALIGN, dtype=torch.float32, device=device)
+            out_offsets = torch.tensor(starts, dtype=torch.int64).to(device, non_blocking=True)
+        out_lengths = torch.empty(B, dtype=torch.int32, device=device)
+        ws_bytes = ctypes.c_size_t()
+        _lib.check(L.sttfe_preprocess_workspace_bytes(B, ctypes.byref(ws_bytes)))
+        ws = torch.empty(max(ws_bytes.value, 1), dtype=torch.uint8, device=device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        max_in = max(host_lengths) if B else 0
+        with torch.cuda.device(device):
+            _lib.check(L.sttfe_resample_peak(_lib.ptr(pcm_in), _lib.ptr(in_offsets), _lib.ptr(in_lengths), B,
+                                             int(channels), int(max_in),
+                                             _lib.ptr(plan.on(device)) if plan else None,
+                                             _lib.ptr(plan.host) if plan else None,
+                                             _lib.ptr(pcm_out), _lib.ptr(out_offsets), _lib.ptr(out_lengths),
+                                             _lib.ptr(ws), ws.numel(), stream), "sttfe_resample_peak")
+            _lib.check(L.sttfe_normalize_trim(_lib.ptr(pcm_out), _lib.ptr(out_offsets), _lib.ptr(out_lengths), B,
+                                              int(max(out_lens) if B else 0), int(self.normalize),
+                                              int(self.trim_silence), ctypes.c_float(self.silence_threshold),
+                                              _lib.ptr(ws), ws.numel(), stream), "sttfe_normalize_trim")
+        self.last_peaks = ws[:4 * B].view(torch.float32)      # max|x| per clip before normalisation (debug / tests)
+        if sync_lengths is None:
+            sync_lengths = self.trim_silence
+        final_lens = [int(v) for v in out_lengths.cpu().tolist()] if sync_lengths else out_lens
+        # src/data.py:75,91,95: duration = n / sample_rate after resampling (after trimming when it trimmed)
+        keep = [self.min_duration <= n / self.sample_rate <= self.max_duration for n in final_lens]
+        return PackedAudio(pcm_out, out_offsets, out_lengths, final_lens, self.sample_rate, keep)
+
+    def preprocess_batch(self, clips: Sequence, original_sample_rate: int) -> PackedAudio:
+        """List of (C, n) / (n,) arrays or tensors, all at ``original_sample_rate`` -> PackedAudio."""
+        device = self.device
+        pcm, offsets, lengths, lens, chans = pack_planar(list(clips), device)
+        return self.run(pcm, offsets, lengths, lens, chans, original_sample_rate)
+
+    def preprocess(self, audio, original_sample_rate: int) -> Optional[Dict[str, Any]]:
+        """Single-clip form with the reference's signature and return value (src/data.py:54-108):
+        ``{"audio": (1, n) tensor (on the GPU), "sample_rate", "duration"}`` or None when gated out."""
+        try:
+            packed = self.preprocess_batch([audio], original_sample_rate)
+        except _lib.SttfeError:
+            raise
+        except Exception:
+            return None
+        if not packed.keep[0]:
+            return None
+        return {"audio": packed.clip(0), "sample_rate": self.sample_rate, "duration": packed.durations[0]}
+
+    def __repr__(self) -> str:
+        return (f"GpuAudioPreprocessor(sample_rate={self.sample_rate}, normalize={self.normalize}, "
+                f"trim_silence={self.trim_silence})")
