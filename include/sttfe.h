@@ -58,7 +58,7 @@ int sttfe_whisper_tables_build(int n_mels, void* host_blob, size_t bytes);
 /* The dense (n_mels x 201) float32 mel bank the tables were derived from (for inspection/tests). */
 int sttfe_whisper_mel_bank(int n_mels, float* host_dense);
 
-/* Bytes of device workspace needed for a batch (per-clip max keys). */
+/* Bytes of device workspace needed for a batch (per-clip max key + per-tile min keys). */
 int sttfe_whisper_workspace_bytes(int batch, size_t* bytes);
 
 /*
@@ -155,9 +155,9 @@ int sttfe_normalize_trim(float* pcm, int64_t* offsets, int32_t* lengths, int bat
                          int normalize, int trim, float silence_threshold,
                          void* workspace, size_t workspace_bytes, void* stream);
 
-/* Clips per launch pair of sttfe_whisper_logmel (default 96): kernel 1's output for a chunk should
- * still be in the 256 MiB Infinity Cache when the clamp kernel re-reads it.  Tuning knob. */
-int sttfe_set_whisper_chunk(int clips);
+/* Consecutive 48-frame tiles one workgroup of the STFT kernel walks (default 9; 0 restores it).
+ * Tuning knob, no counterpart in the reference. */
+int sttfe_set_whisper_tiles_per_block(int tiles);
 
 /* ------------------------------------------------------------- measurement support -----------
  * No counterpart in the reference.  Optional per-kernel timing with HIP events recorded on the

@@ -11,7 +11,8 @@ import torch  # noqa: F401
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsttfe.so")
+# STTFE_LIB_PATH selects another build of the same library (kernel A/B experiments); never a fallback
+LIB_PATH = os.environ.get("STTFE_LIB_PATH") or os.path.join(_HERE, "libsttfe.so")
 
 _lib = None
 
@@ -32,7 +33,7 @@ def _declare(lib):
         "sttfe_whisper_mel_bank": [c_int, p],
         "sttfe_whisper_workspace_bytes": [c_int, POINTER(c_size_t)],
         "sttfe_whisper_logmel": [p, p, p, c_int, c_int, c_int, p, p, p, c_int, p, c_size_t, p],
-        "sttfe_set_whisper_chunk": [c_int],
+        "sttfe_set_whisper_tiles_per_block": [c_int],
         "sttfe_timing_enable": [c_int],
         "sttfe_timing_reset": [],
         "sttfe_timing_query": [c_char_p, POINTER(ctypes.c_double), POINTER(c_int)],

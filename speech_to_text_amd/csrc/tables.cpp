@@ -68,7 +68,7 @@ void kaldi_mel_bank(int n_mels, std::vector<float>& dense) {
 
 // Build the banded MFMA plan + A fragments from a dense (n_mels x n_bins) bank times `scale`.
 void build_mel_plan(const std::vector<float>& dense, int n_mels, int n_bins, float scale,
-                    int n_waves, int n_ftiles, MelPlan& plan, std::vector<float>& afrag) {
+                    int n_waves, int n_ftiles, int step_multiple, MelPlan& plan, std::vector<float>& afrag) {
     std::memset(&plan, 0, sizeof(plan));
     plan.n_mels = n_mels;
     plan.n_bins = n_bins;
@@ -88,7 +88,10 @@ void build_mel_plan(const std::vector<float>& dense, int n_mels, int n_bins, flo
         int nsteps = 0, kstart = 0;
         if (hi >= lo) {
             nsteps = (hi - lo + 1 + 3) / 4;
-            kstart = std::max(0, std::min(lo, n_bins - 4 * nsteps));   // never read past bin n_bins-1
+            // zero-weight steps pad the band to a multiple of step_multiple (the kernel batches its loads)
+            nsteps = (nsteps + step_multiple - 1) / step_multiple * step_multiple;
+            // never read past the row: the panel row holds n_bins values + 1 finite pad cell
+            kstart = std::max(0, std::min(lo, n_bins + 1 - 4 * nsteps));
         }
         plan.kstart[mt] = kstart;
         plan.nsteps[mt] = nsteps;
@@ -139,7 +142,7 @@ static int whisper_tables(int n_mels, std::vector<unsigned char>& blob) {
     std::memset(&h, 0, sizeof(h));
     // 0.25 = the 1/4 of the two-real-frames-in-one-complex-FFT separation, folded into the bank
     // (a power of two: bit-identical to scaling the power spectrum itself).
-    build_mel_plan(dense, n_mels, 201, 0.25f, kWavesPerBlock, kFrameTiles, h.plan, afrag);
+    build_mel_plan(dense, n_mels, 201, 0.25f, 4, kFrameTiles, 4, h.plan, afrag);   // 4 waves x 3 frame tiles
     h.magic = kWhisperMagic;
     h.n_mels = n_mels;
     h.afrag_floats = (int32_t)afrag.size();
@@ -192,7 +195,7 @@ static int kaldi_tables(int n_mels, std::vector<unsigned char>& blob) {
     std::memset(&h, 0, sizeof(h));
     // 2^28 = (2^15)^2 [the x * 2**15 of HF speech_to_text.py:112 applied to the power spectrum] * 1/4
     // [two-real-frames separation]; a power of two, so folding it into the bank is exact.
-    build_mel_plan(dense, n_mels, 257, 268435456.0f, 4, 2, h.plan, afrag);
+    build_mel_plan(dense, n_mels, 257, 268435456.0f, 4, 2, 1, h.plan, afrag);
     h.magic = kKaldiMagic;
     h.n_mels = n_mels;
     h.afrag_floats = (int32_t)afrag.size();

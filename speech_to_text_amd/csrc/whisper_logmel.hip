@@ -1,30 +1,35 @@
 // Whisper log-mel front-end for gfx950 (MI355X): framing + Hann + 400-point STFT + mel + log10,
-// then a per-clip clamp(max - 8) / (x + 4) / 4 (+ optional SpecAugment masks) fix-up pass.
+// then the per-clip clamp(max - 8) / (x + 4) / 4 fix-up (+ SpecAugment masks, + 30 s zero padding).
 //
 // Replaces HF WhisperFeatureExtractor._torch_extract_fbank_features
 // (HF:models/whisper/feature_extraction_whisper.py:135-168) as reached from the reference at
 // src/data.py:338-343, inference.py:148-152 and src/processors.py:180-221.
 //
-// Kernel 1 (stft_mel): one 512-thread workgroup (8 waves) per 48-frame tile of one clip.
-//   * A wave owns 6 frames = 3 pairs; two real frames a, b are packed as z = a + i b and
-//     transformed by ONE complex 400-point DFT, factored 20 x 20: lane (p, j) of a pair first runs
-//     a register-resident 20-point DFT over n1 of z[20 n1 + j] (fft_core.h, twiddle-free 4 x 5
-//     prime-factor form), multiplies by W_400^(j k1), exchanges through a wave-private,
-//     bank-conflict-free LDS slab ([pair][k1][n2], row stride 21, pair stride 420 float2), and runs
-//     the second 20-point DFT over n2.  Lane j then holds Z[j + 20 k2]; the spectra of a and b are
-//     separated with one cross-lane exchange (lane j <-> lane 20 - j) and only bins 0..200 kept.
-//   * |A|^2, |B|^2 go to a [frame][bin] LDS panel (row stride 202 floats: conflict-free for both
-//     the scattered writes and the MFMA operand reads) that aliases the FFT slabs.
-//   * The mel projection is a banded product on the matrix cores: exact-f32
-//     v_mfma_f32_16x16x4_f32 tiles (16 mel rows x 16 frames), only over the bins each 16-row band
-//     of the triangular bank touches (57 of 255 k-steps for 80 mels); (mel tile, frame tile) units
-//     are spread over the 8 waves by a host-built plan (tables.cpp).
-//   * Epilogue per tile: log10(max(mel, 1e-10)) -> (x + 4) / 4 stored unclamped; the running
-//     per-clip max of log10 goes to a per-clip key with ONE atomicMax per wave.
-//   Tiles that lie entirely in the zero padding skip the FFT and store the constant.
-// Kernel 2 (clamp_mask): streams the clip's output once, applies max(y, (max - 8 + 4) / 4) and the
-//   SpecAugment masks.  Launched per chunk of clips small enough that kernel 1's output is still
-//   in the 256 MiB Infinity Cache.
+// Kernel 1 (stft_mel): 256-thread workgroups (4 waves), three per CU (45 KB LDS, <= 168 VGPRs each).
+//   A workgroup walks a run of consecutive 48-frame tiles of one clip.  Per tile:
+//   * every wave makes two passes of 3 frame pairs (12 frames).  Two real frames a, b are packed as
+//     z = a + i b and transformed by ONE complex 400-point DFT, factored 20 x 20: lane (p, j) of a pair
+//     runs a register-resident 20-point DFT over n1 of z[20 n1 + j] (fft_core.h, twiddle-free 4 x 5
+//     prime-factor form), multiplies by W_400^(j k1) (table in LDS), exchanges through a wave-private,
+//     bank-conflict-free LDS slab ([pair][k1][n2], row stride 21, pair stride 420 float2) and runs the
+//     second 20-point DFT over n2.  Lane j then holds Z[j + 20 k2]; the spectra of a and b are
+//     separated with one cross-lane exchange (lane j <-> lane 20 - j), bins 0..200 kept.
+//     The PCM of the NEXT pass is loaded into registers at the start of each pass, so a full pass of
+//     arithmetic hides the HBM latency; the window column lives in registers.
+//   * |A|^2, |B|^2 of both passes stay in registers until the wave's last slab read, then go to the
+//     wave's own 12 rows of the [frame][bin] power panel (row stride 202 floats), which aliases the
+//     wave's own slab: no workgroup barrier between FFT and panel.
+//   * barrier; banded mel projection on the matrix cores: exact-f32 v_mfma_f32_16x16x4_f32 tiles
+//     (16 mel rows x 16 frames) over only the bins each 16-row band of the triangular bank touches
+//     (53 k-steps for 80 mels, 56 for 128); (mel tile, frame tile) units are spread over the 4 waves
+//     by a host-built plan (tables.cpp); barrier.
+//   * epilogue: log10(max(mel, 1e-10)) -> (x + 4) / 4 stored unclamped with the SpecAugment masks
+//     applied from per-tile / per-clip bit masks; per-clip max and per-tile min of log10 go to the
+//     workspace with one atomic per wave.
+//   Tiles that lie entirely in the 30 s zero padding are left to kernel 2 (they are constant).
+// Kernel 2 (clamp_fill): one small workgroup per (clip, tile).  Padding tiles are filled with the final
+//   constant (write only); a computed tile is re-read and clamped to (max - 8 + 4) / 4 only when its
+//   recorded minimum is below max - 8 (otherwise it is already final and the workgroup exits).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -35,24 +40,36 @@
 
 namespace sttfe {
 
-constexpr int kThreads = 512;
+namespace wh {
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
 constexpr int kTileFrames = 48;
-constexpr int kFramesPerWave = 6;
+constexpr int kFramesPerWave = 12;            // two passes of 3 pairs
 constexpr int kHop = 160;
 constexpr int kNfft = 400;
-constexpr int kMaxSamples = 480000;          // 30 s at 16 kHz (HF:...whisper.py:91)
-constexpr int kRowStride = 21;               // float2 units, [k1][n2] rows
-constexpr int kPairStride = 420;             // float2 units per frame pair (== 4 mod 32)
-constexpr int kSlabPerWave = 3 * kPairStride;
-constexpr int kPStride = 202;                // floats per frame row of the power panel (== 10 mod 16)
-constexpr int kLdsBytes = kWavesPerBlock * kSlabPerWave * 8;     // 80640 B -> 2 workgroups per CU
-static_assert(kTileFrames * kPStride * 4 <= kLdsBytes, "power panel must fit inside the FFT slabs");
+constexpr int kMaxSamples = 480000;           // 30 s at 16 kHz (HF:...whisper.py:91)
+constexpr int kMaxTiles = 63;                 // ceil(3000 / 48)
+constexpr int kKeysPerClip = 64;              // workspace: [0] = max key, [1 + r] = ~min key of tile run r
+constexpr int kRowStride = 21;                // float2 units, [k1][n2] rows
+constexpr int kPairStride = 420;              // float2 units per frame pair (== 4 mod 32)
+constexpr int kSlabFloats = 3 * kPairStride * 2;      // 2520 floats per wave
+constexpr int kPStride = 202;                 // floats per frame row of the power panel (== 10 mod 32)
+static_assert(kFramesPerWave * kPStride <= kSlabFloats, "a wave's panel rows must fit inside its own slab");
+static_assert((kSlabFloats - kFramesPerWave * kPStride) % 32 == 0, "panel rows keep one bank pattern across waves");
+constexpr int kWinOff = kWaves * kSlabFloats;         // float offsets of the tables inside the LDS array
+constexpr int kTwOff = kWinOff + 400;
+constexpr int kAfragOff = kTwOff + 800;               // banded mel weights in MFMA A-operand order
+constexpr int kMaxAfragFloats = 4096;                 // 53 (80 mels) / 56 (128 mels) k-steps x 64 lanes
+constexpr int kDescOff = kAfragOff + kMaxAfragFloats;     // per wave: 8 x {kstart, nsteps, aoff, mt | ft << 8}, then the unit counts
+constexpr int kLdsFloats = kDescOff + kWaves * kMaxUnitsPerWave * 4 + kWaves;   // 62032 B -> 2 workgroups per CU
+}  // namespace wh
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int int4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned float_to_key(float f) {
     unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // order-preserving float -> uint
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // order-preserving float -> uint, never 0 for finite f
 }
 __device__ __forceinline__ float key_to_float(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
@@ -66,101 +83,171 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(kThreads, 4) void whisper_stft_mel_kernel(
-    const float* __restrict__ pcm, const int64_t* __restrict__ offsets,
-    const int32_t* __restrict__ lengths, int clip0, int n_mels, int n_frames,
-    const WhisperTablesHeader* __restrict__ tab, float* __restrict__ out,
-    unsigned* __restrict__ max_keys, int tiles_per_block) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsBytes];
-    cf* slab_all = reinterpret_cast<cf*>(smem);
-    float* panel = reinterpret_cast<float*>(smem);
+// Bits [0, width) of the result mark the indices base + i covered by a mask of the given axis.
+__device__ __forceinline__ uint64_t mask_bits(const int32_t* __restrict__ m, int n_masks, int axis, int base, int width) {
+    uint64_t bits = 0;
+    for (int i = 0; i < n_masks; ++i) {
+        if (m[3 * i] != axis) continue;
+        int s = m[3 * i + 1] - base, e = m[3 * i + 2] - base;
+        s = s < 0 ? 0 : s;
+        e = e > width ? width : e;
+        if (e > s) bits |= ((e - s >= 64) ? ~0ull : ((1ull << (e - s)) - 1ull)) << s;
+    }
+    return bits;
+}
 
-    const int clip = clip0 + blockIdx.y;
+#ifdef STTFE_STAMPS
+// Diagnostic build only: per-wave cycle sums of each phase of the tile loop (never in the product build).
+__device__ unsigned long long* g_stamp_buf = nullptr;
+#define STAMP(i)                                                                 \
+    do {                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        unsigned long long t_;                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        stamp_sum[i] += t_ - stamp_prev;                                         \
+        stamp_prev = t_;                                                         \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+
+#ifndef STTFE_WH_WAVES_PER_SIMD
+#define STTFE_WH_WAVES_PER_SIMD 2
+#endif
+__global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper_stft_mel_kernel(
+    const float* __restrict__ pcm, const int64_t* __restrict__ offsets,
+    const int32_t* __restrict__ lengths, int n_mels, int n_frames,
+    const WhisperTablesHeader* __restrict__ tab, float* __restrict__ out,
+    unsigned* __restrict__ keys, const int32_t* __restrict__ mask_tbl, int n_masks, int tiles_per_block) {
+    using namespace wh;
+    __shared__ __attribute__((aligned(16))) float smem[kLdsFloats];
+
+    const int clip = blockIdx.y;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = lane / 20;                 // pair within the wave (3 = idle lanes 60..63)
     const int j = lane - p * 20;
     const bool active = lane < 60;
+    const int pa_ = active ? p : 0;
 
-    const float* __restrict__ x = pcm + offsets[clip];
     int n_valid = lengths[clip];
     n_valid = n_valid < 0 ? 0 : (n_valid > kMaxSamples ? kMaxSamples : n_valid);
-
-    const float* __restrict__ afrag = reinterpret_cast<const float*>(tab + 1);
-    const MelPlan& plan = tab->plan;
-
-    // Per-lane constants (window column j, twiddles W_400^(j k1)) are re-read from the L1-resident
-    // tables every tile instead of living in 60 VGPRs: the loads are lane-contiguous (80 / 160 B).
-    const float* __restrict__ win_col = tab->window + j;
-    const cf* __restrict__ tw_col = reinterpret_cast<const cf*>(tab->twiddle) + j;
-    const int partner = active ? (p * 20 + ((20 - j) % 20)) : lane;
-    cf* slab = slab_all + wave * kSlabPerWave + (active ? p : 0) * kPairStride;
-
-    float run_max = -3.0e38f;
     const int n_tiles = (n_frames + kTileFrames - 1) / kTileFrames;
     const int tile_begin = blockIdx.x * tiles_per_block;
-    const int tile_end = min(tile_begin + tiles_per_block, n_tiles);
+    int tile_end = min(tile_begin + tiles_per_block, n_tiles);
+    // tiles whose first sample lies in the zero padding are constant: kernel 2 fills them
+    const int first_pad_tile = (n_valid + kNfft / 2 + kHop * kTileFrames - 1) / (kHop * kTileFrames);
+    tile_end = min(tile_end, first_pad_tile);
+    if (tile_begin >= tile_end) return;
 
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
-        const int t0 = tile * kTileFrames;
-        const int first_sample = kHop * t0 - kNfft / 2;
-        float* __restrict__ out_clip = out + (size_t)clip * n_mels * n_frames;
-
-        if (first_sample >= n_valid) {
-            // Whole tile reads only zero padding: mel = 0 -> log10(1e-10) = -10 -> (x + 4) / 4.
-            const int width = min(kTileFrames, n_frames - t0);
-            for (int e = tid; e < n_mels * kTileFrames; e += kThreads) {
-                const int m = e / kTileFrames, f = e - m * kTileFrames;
-                if (f < width) out_clip[(size_t)m * n_frames + t0 + f] = -1.5f;
-            }
-            run_max = fmaxf(run_max, -10.0f);
-            continue;
+    // zero the slabs once (pad cells are read by zero-weight MFMA steps and must be finite), stage tables
+    for (int i = tid; i < kWinOff; i += kThreads) smem[i] = 0.f;
+    for (int i = tid; i < 400; i += kThreads) smem[kWinOff + i] = tab->window[i];
+    for (int i = tid; i < 800; i += kThreads) smem[kTwOff + i] = tab->twiddle[i];
+    {
+        const float* __restrict__ afrag_g = reinterpret_cast<const float*>(tab + 1);
+        const int na = min(tab->afrag_floats, kMaxAfragFloats);
+        for (int i = tid; i < na; i += kThreads) smem[kAfragOff + i] = afrag_g[i];
+        int* desc = reinterpret_cast<int*>(smem + kDescOff);
+        if (tid < kWaves * kMaxUnitsPerWave) {
+            const int w = tid / kMaxUnitsPerWave, u = tid - w * kMaxUnitsPerWave;
+            const int code = tab->plan.wave_units[w][u], mt = code & 0xff;
+            const bool ok = u < tab->plan.wave_nunits[w];
+            desc[4 * tid + 0] = ok ? tab->plan.kstart[mt] : 0;
+            desc[4 * tid + 1] = ok ? tab->plan.nsteps[mt] : 0;
+            desc[4 * tid + 2] = ok ? tab->plan.aoff[mt] : 0;
+            desc[4 * tid + 3] = code;
         }
+        if (tid < kWaves) desc[4 * kWaves * kMaxUnitsPerWave + tid] = tab->plan.wave_nunits[tid];
+    }
+    __syncthreads();
 
-        // ---------------- load 28 samples per lane (frame a = n1 0..19, frame b = n1 8..27) ----
-        const int fa = t0 + wave * kFramesPerWave + 2 * (active ? p : 0);
-        const int base = kHop * fa - kNfft / 2 + j;
-        float raw[28];
-        const bool interior = (first_sample >= 0) &&
-                              (kHop * (t0 + kTileFrames - 1) - kNfft / 2 + kNfft <= n_valid);
-        if (interior) {
+    const float* __restrict__ x = pcm + offsets[clip];
+    float* __restrict__ out_clip = out + (size_t)clip * n_mels * n_frames;
+    const float* afrag = smem + kAfragOff;
+    const int4v* desc = reinterpret_cast<const int4v*>(smem + kDescOff) + wave * kMaxUnitsPerWave;
+    const int nu = __builtin_amdgcn_readfirstlane(
+        reinterpret_cast<const int*>(smem + kDescOff)[4 * kWaves * kMaxUnitsPerWave + wave]);
+    const cf* tw_col = reinterpret_cast<const cf*>(smem + kTwOff) + j;
+    const int partner = active ? (p * 20 + ((20 - j) % 20)) : lane;
+    cf* slab = reinterpret_cast<cf*>(smem + wave * kSlabFloats) + pa_ * kPairStride;
+    float* my_rows = smem + wave * kSlabFloats;
+
+#ifdef STTFE_WIN_REGS
+    float win[20];
 #pragma unroll
-            for (int m = 0; m < 28; ++m) raw[m] = x[base + 20 * m];
+    for (int i = 0; i < 20; ++i) win[i] = smem[kWinOff + 20 * i + j];
+#else
+    const float* win = smem + kWinOff + j;
+#endif
+
+    // SpecAugment: mel-axis masks as two 64-bit words for the clip; time-axis masks per tile
+    const int32_t* __restrict__ clip_masks = mask_tbl ? mask_tbl + (size_t)clip * n_masks * 3 : nullptr;
+    const int nm = clip_masks ? n_masks : 0;
+    const uint64_t melmask_lo = mask_bits(clip_masks, nm, STTFE_AXIS_FREQ, 0, 64);
+    const uint64_t melmask_hi = mask_bits(clip_masks, nm, STTFE_AXIS_FREQ, 64, 64);
+
+    // 28 samples per lane and pass: frame a = rows 0..19, frame b = rows 8..27 of x[base + 20 m]
+    auto load_pass = [&](int t0, int pass, float (&r)[28]) {
+        const int f0 = t0 + wave * kFramesPerWave + 6 * pass;          // first frame of the pass (wave-uniform)
+        const int first = kHop * f0 - kNfft / 2;
+        const int base = first + 2 * kHop * pa_ + j;
+        if (first >= 0 && first + 5 * kHop + kNfft <= n_valid) {
+#ifdef ABL_NOLOAD
+#pragma unroll
+            for (int m = 0; m < 28; ++m) r[m] = (float)(base + m) * 1e-7f;
+#else
+#pragma unroll
+            for (int m = 0; m < 28; ++m) r[m] = x[base + 20 * m];
+#endif
         } else {
 #pragma unroll
             for (int m = 0; m < 28; ++m) {
                 int idx = base + 20 * m;
-                idx = idx < 0 ? -idx : idx;                       // reflect padding (center=True) ...
-                idx = idx >= kMaxSamples ? 2 * (kMaxSamples - 1) - idx : idx;   // ... of the 30 s buffer
-                raw[m] = (idx < n_valid) ? x[idx] : 0.0f;         // zero padding to 30 s
+                idx = idx < 0 ? -idx : idx;                                       // reflect padding (center=True) ...
+                idx = idx >= kMaxSamples ? 2 * (kMaxSamples - 1) - idx : idx;     // ... of the 30 s buffer
+                r[m] = (idx < n_valid) ? x[idx] : 0.0f;                           // zero padding to 30 s
             }
         }
+    };
 
-        // ---------------- stage 1: 20-point DFT over n1, twiddle, to the slab -------------------
+    // one pass: window, 20 x 20 DFT through the slab, spectra separation -> 4 |A|^2, 4 |B|^2 (bins j + 20 k2)
+    auto fft_stage1 = [&](const float (&raw)[28]) {
         cf v[20], y[20];
-        int keep = 0;
-        asm volatile("" : "+v"(keep));    // keeps the table loads inside the tile loop (no hoist -> no spills)
 #pragma unroll
         for (int i = 0; i < 20; ++i) {
-            const float w = win_col[20 * i + keep];
+#ifdef STTFE_WIN_REGS
+            const float w = win[i];
+#else
+#ifdef ABL_NOWIN
+            const float w = 0.5f + i;
+#else
+            const float w = win[20 * i];
+#endif
+#endif
             v[i] = cf{raw[i] * w, raw[i + 8] * w};
         }
+        // all twiddle reads are issued before the first slab write: the compiler cannot move an LDS read
+        // above an LDS write of the same array, and one read-wait-write round trip per row costs ~1k cycles
+        cf tw[20];
+#pragma unroll
+        for (int k1 = 1; k1 < 20; ++k1) tw[k1] = tw_col[20 * k1];
         dft20(v, y);
         if (active) {
             slab[j] = y[0];
 #pragma unroll
-            for (int k1 = 1; k1 < 20; ++k1) slab[k1 * kRowStride + j] = cmul(y[k1], tw_col[20 * k1 + keep]);
+            for (int k1 = 1; k1 < 20; ++k1) slab[k1 * kRowStride + j] = cmul(y[k1], tw[k1]);
         }
         wave_lds_sync();
-
-        // ---------------- stage 2: 20-point DFT over n2 --------------------------------------
+    };
+    auto fft_stage2 = [&](float (&pa)[11], float (&pb)[11]) {
+        cf v[20], y[20];
 #pragma unroll
         for (int n2 = 0; n2 < 20; ++n2) v[n2] = slab[j * kRowStride + n2];
+        wave_lds_sync();      // the next writes to the slab (next pass / panel rows) come after these reads
         dft20(v, y);          // y[k2] = Z[j + 20 k2]
-
-        // ---------------- separate the two real spectra, power, bins 0..200 ----------------------
-        float pa[11], pb[11];
 #pragma unroll
         for (int k2 = 0; k2 < 10; ++k2) {
             float qr = __shfl(y[19 - k2].x, partner, 64);
@@ -176,90 +263,211 @@ __global__ __launch_bounds__(kThreads, 4) void whisper_stft_mel_kernel(
         }
         pa[10] = 4.0f * y[10].x * y[10].x;                        // bin 200 (lane j == 0 only)
         pb[10] = 4.0f * y[10].y * y[10].y;
+    };
 
-        __syncthreads();      // every wave is done reading its slab: the panel may overwrite them
-        if (active) {
-            float* row = panel + (wave * kFramesPerWave + 2 * p) * kPStride + j;
+    auto store_rows = [&](int pass, const float (&pa)[11], const float (&pb)[11]) {
+        if (!active) return;
+        float* row = my_rows + (6 * pass + 2 * p) * kPStride + j;
 #pragma unroll
-            for (int k2 = 0; k2 < 10; ++k2) {
-                row[20 * k2] = pa[k2];
-                row[kPStride + 20 * k2] = pb[k2];
-            }
-            if (j == 0) {
-                row[200] = pa[10];
-                row[kPStride + 200] = pb[10];
-            }
+        for (int k2 = 0; k2 < 10; ++k2) {
+            row[20 * k2] = pa[k2];
+            row[kPStride + 20 * k2] = pb[k2];
         }
-        __syncthreads();
+        if (j == 0) {
+            row[200] = pa[10];
+            row[kPStride + 200] = pb[10];
+        }
+    };
+
+#ifdef EXP_DEPHASE
+    if ((blockIdx.x + blockIdx.y) & 1) {
+        for (int i = 0; i < EXP_DEPHASE; ++i) __builtin_amdgcn_s_sleep(127);     // ~127 * 64 cycles each
+    }
+#endif
+    float run_max = -3.0e38f, run_min = 3.0e38f;
+    // LDS float offset of this lane's B-operand row (frame ft * 16 + (lane & 15), k = lane >> 4) per frame tile
+    auto b_row = [&](int ft) {
+        const int fl = ft * 16 + (lane & 15), fw = fl / kFramesPerWave;
+        return fw * kSlabFloats + (fl - fw * kFramesPerWave) * kPStride + (lane >> 4);
+    };
+    const int brow0 = b_row(0), brow1 = b_row(1), brow2 = b_row(2);
+    float raw0[28], raw1[28];                      // the two passes of the NEXT tile, loaded a whole tile ahead
+    load_pass(tile_begin * kTileFrames, 0, raw0);
+    load_pass(tile_begin * kTileFrames, 1, raw1);
+#ifdef STTFE_STAMPS
+    unsigned long long stamp_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        const int t0 = tile * kTileFrames;
+        float pa0[11], pb0[11], pa1[11], pb1[11];
+        const bool more = tile + 1 < tile_end;
+
+        fft_stage1(raw0);
+        STAMP(0);
+        if (more) load_pass(t0 + kTileFrames, 0, raw0);
+        fft_stage2(pa0, pb0);
+        STAMP(2);
+        fft_stage1(raw1);
+        STAMP(3);
+        if (more) load_pass(t0 + kTileFrames, 1, raw1);
+        fft_stage2(pa1, pb1);
+        STAMP(4);
+
+        store_rows(0, pa0, pb0);
+        store_rows(1, pa1, pb1);
+        STAMP(5);
+        __syncthreads();                                           // panel complete
+        STAMP(6);
 
         // ---------------- banded mel projection on the matrix cores + log epilogue --------------
-        const int nu = plan.wave_nunits[wave];
+        const uint64_t tmask = mask_bits(clip_masks, nm, STTFE_AXIS_TIME, t0, kTileFrames);
+        int4v d = desc[0];                                          // {kstart, nsteps, aoff, mt | ft << 8}
         for (int u = 0; u < nu; ++u) {
-            const int code = plan.wave_units[wave][u];
+            const int ks = __builtin_amdgcn_readfirstlane(d.x);
+            const int ns = __builtin_amdgcn_readfirstlane(d.y);     // multiple of 4 (tables.cpp)
+            const int ao = __builtin_amdgcn_readfirstlane(d.z);
+            const int code = __builtin_amdgcn_readfirstlane(d.w);
+            d = desc[min(u + 1, kMaxUnitsPerWave - 1)];             // next unit's descriptor lands during this one
             const int mt = code & 0xff, ft = code >> 8;
-            const int ks = plan.kstart[mt], ns = plan.nsteps[mt];
-            const float* __restrict__ a_ptr = afrag + plan.aoff[mt] + lane;
-            const float* b_ptr = panel + (ft * 16 + (lane & 15)) * kPStride + ks + (lane >> 4);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int s = 0; s < ns; ++s)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_ptr[s * 64], b_ptr[4 * s], acc, 0, 0, 0);
-            const int frame = t0 + ft * 16 + (lane & 15);
-            const int mel0 = mt * 16 + (lane >> 4) * 4;
+            const float* a_ptr = afrag + ao + lane;
+            const float* b_ptr = smem + (ft == 0 ? brow0 : (ft == 1 ? brow1 : brow2)) + ks;
+            // two interleaved accumulation chains hide the 40-cycle dependent latency of the 16x16x4 MFMA;
+            // the operands of the next four steps are read while the current four multiply
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+            float av[4], bv[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int mel = mel0 + r;
-                if (mel < n_mels && frame < n_frames) {
-                    const float lg = __log2f(fmaxf(acc[r], 1e-10f)) * 0.30102999566398120f;
-                    run_max = fmaxf(run_max, lg);
-                    out_clip[(size_t)mel * n_frames + frame] = (lg + 4.0f) * 0.25f;
+            for (int i = 0; i < 4; ++i) {
+                av[i] = a_ptr[i * 64];
+                bv[i] = b_ptr[4 * i];
+            }
+            for (int s = 4; s < ns; s += 4) {
+                float an[4], bn[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    an[i] = a_ptr[(s + i) * 64];
+                    bn[i] = b_ptr[4 * (s + i)];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i + 1], bv[i + 1], acc2, 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    av[i] = an[i];
+                    bv[i] = bn[i];
                 }
             }
-        }
-        __syncthreads();      // panel reads done before the next tile's slab writes
-    }
-
-    // one atomic per wave
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) run_max = fmaxf(run_max, __shfl_xor(run_max, off, 64));
-    if (lane == 0 && tile_begin < tile_end) atomicMax(&max_keys[clip], float_to_key(run_max));
+            for (int i = 0; i < 4; i += 2) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i + 1], bv[i + 1], acc2, 0, 0, 0);
+            }
+            acc += acc2;
+            STAMP(9);
+            const int fl = ft * 16 + (lane & 15);                  // frame within the tile
+            const int mel0 = mt * 16 + (lane >> 4) * 4;
+            const unsigned o0 = (unsigned)(mel0 * n_frames + t0 + fl);
+            float yv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float lg = __log2f(fmaxf(acc[r], 1e-10f)) * 0.30102999566398120f;
+                yv[r] = lg;
+            }
+            const bool whole = (mt * 16 + 16 <= n_mels) && (t0 + ft * 16 + 16 <= n_frames);    // wave-uniform
+            if (whole && nm == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    run_max = fmaxf(run_max, yv[r]);
+                    run_min = fminf(run_min, yv[r]);
+                    out_clip[o0 + (unsigned)(r * n_frames)] = (yv[r] + 4.0f) * 0.25f;
+                }
+            } else {
+                const bool tmasked = (tmask >> fl) & 1ull;
+                const unsigned mbits = (unsigned)((mel0 < 64 ? melmask_lo >> mel0 : melmask_hi >> (mel0 - 64)) & 15ull);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (mel0 + r < n_mels && t0 + fl < n_frames) {
+                        run_max = fmaxf(run_max, yv[r]);
+                        run_min = fminf(run_min, yv[r]);
+                        out_clip[o0 + (unsigned)(r * n_frames)] =
+                            (tmasked || ((mbits >> r) & 1u)) ? 0.0f : (yv[r] + 4.0f) * 0.25f;
+                    }
+                }
+            }
+            STAMP(1);
+        }
+        STAMP(7);
+        __syncthreads();      // panel reads done before the next tile's slab writes
+        STAMP(8);
+    }
+#ifdef STTFE_STAMPS
+    if (g_stamp_buf && lane == 0) {
+        unsigned long long* dst = g_stamp_buf + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kWaves + wave) * 10;
+        for (int i = 0; i < 10; ++i) dst[i] = stamp_sum[i];
+    }
+#endif
+
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        run_max = fmaxf(run_max, __shfl_xor(run_max, off, 64));
+        run_min = fminf(run_min, __shfl_xor(run_min, off, 64));
+    }
+    if (lane == 0) {
+        atomicMax(&keys[(size_t)clip * kKeysPerClip], float_to_key(run_max));
+        atomicMax(&keys[(size_t)clip * kKeysPerClip + 1 + blockIdx.x], ~float_to_key(run_min));
+    }
 }
 
-// y <- max(y, ((max - 8) + 4) / 4); SpecAugment masks -> 0.0.  One workgroup column per clip.
-__global__ __launch_bounds__(256) void whisper_clamp_mask_kernel(
-    float* __restrict__ out, const unsigned* __restrict__ max_keys, int clip0, int n_mels,
-    int n_frames, const int32_t* __restrict__ mask_tbl, int n_masks) {
-    const int clip = clip0 + blockIdx.y;
-    const float lmax = key_to_float(max_keys[clip]);
-    const float floor_y = ((lmax - 8.0f) + 4.0f) * 0.25f;
-    float* __restrict__ o = out + (size_t)clip * n_mels * n_frames;
-    const int total = n_mels * n_frames;
-    int m_axis[8], m_s[8], m_e[8];
-    const int nm = mask_tbl ? (n_masks > 8 ? 8 : n_masks) : 0;
-    for (int i = 0; i < nm; ++i) {
-        const int32_t* m = mask_tbl + ((size_t)clip * n_masks + i) * 3;
-        m_axis[i] = m[0];
-        m_s[i] = m[1];
-        m_e[i] = m[2];
+// One workgroup per (tile, clip): fill padding tiles with the final constant, clamp computed tiles whose
+// minimum is below max - 8; SpecAugment masks -> 0.0 on everything it writes.
+__global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
+    float* __restrict__ out, const int32_t* __restrict__ lengths, const unsigned* __restrict__ keys,
+    int n_mels, int n_frames, const int32_t* __restrict__ mask_tbl, int n_masks, int tiles_per_block) {
+    using namespace wh;
+    const int clip = blockIdx.y, tile = blockIdx.x;
+    int n_valid = lengths[clip];
+    n_valid = n_valid < 0 ? 0 : (n_valid > kMaxSamples ? kMaxSamples : n_valid);
+    const unsigned kmax = keys[(size_t)clip * kKeysPerClip];
+    const float lmax = kmax ? key_to_float(kmax) : -10.0f;        // no computed tile at all: log10(1e-10)
+    const float floor_lg = lmax - 8.0f;
+    const float floor_y = (floor_lg + 4.0f) * 0.25f;
+    const int t0 = tile * kTileFrames;
+    const int width = min(kTileFrames, n_frames - t0);
+    const bool padding = kHop * t0 - kNfft / 2 >= n_valid;
+    if (!padding) {
+        // minimum over the run of tiles one kernel-1 workgroup walked
+        const unsigned kmin = ~keys[(size_t)clip * kKeysPerClip + 1 + tile / tiles_per_block];
+        if (key_to_float(kmin) >= floor_lg) return;               // nothing in this run is below the floor
     }
-    const int stride = gridDim.x * blockDim.x * 4;
-    for (int e = (blockIdx.x * blockDim.x + threadIdx.x) * 4; e < total; e += stride) {
-        // rows are n_frames long and n_frames % 4 == 0 is required by the host wrapper, so the
-        // four elements share a mel row and the clip base is 16-byte aligned.
-        f32x4 v = *reinterpret_cast<f32x4*>(o + e);
-        f32x4 w;
-        const int mel = e / n_frames, fr = e - mel * n_frames;
-        bool changed = false;
+    const float pad_y = fmaxf((-10.0f + 4.0f) * 0.25f, floor_y);
+    const int32_t* __restrict__ clip_masks = mask_tbl ? mask_tbl + (size_t)clip * n_masks * 3 : nullptr;
+    const int nm = clip_masks ? n_masks : 0;
+    const uint64_t tmask = mask_bits(clip_masks, nm, STTFE_AXIS_TIME, t0, kTileFrames);
+    const uint64_t melmask_lo = mask_bits(clip_masks, nm, STTFE_AXIS_FREQ, 0, 64);
+    const uint64_t melmask_hi = mask_bits(clip_masks, nm, STTFE_AXIS_FREQ, 64, 64);
+    float* __restrict__ o = out + (size_t)clip * n_mels * n_frames + t0;
+    // rows are n_frames floats long with n_frames % 4 == 0 and t0 % 4 == 0: float4 accesses are aligned
+    const int quads = width >> 2;
+    for (int e = threadIdx.x; e < n_mels * quads; e += blockDim.x) {
+        const int mel = e / quads, q = e - mel * quads;
+        f32x4* ptr = reinterpret_cast<f32x4*>(o + (size_t)mel * n_frames + 4 * q);
+        const bool mmasked = ((mel < 64 ? melmask_lo >> mel : melmask_hi >> (mel - 64)) & 1ull);
+        f32x4 v, w;
+        if (padding) v = f32x4{pad_y, pad_y, pad_y, pad_y};
+        else v = *ptr;
+        bool changed = padding;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float y = fmaxf(v[c], floor_y);
-            for (int i = 0; i < nm; ++i) {
-                const int idx = (m_axis[i] == STTFE_AXIS_TIME) ? fr + c : mel;
-                if (idx >= m_s[i] && idx < m_e[i]) y = 0.0f;
-            }
+            // masked cells of a computed tile already hold 0.0 and must stay 0.0
+            if (mmasked || ((tmask >> (4 * q + c)) & 1ull)) y = 0.0f;
             changed |= (y != v[c]);
             w[c] = y;
         }
-        if (changed) *reinterpret_cast<f32x4*>(o + e) = w;
+        if (changed) *ptr = w;
     }
 }
 
@@ -267,18 +475,24 @@ __global__ __launch_bounds__(256) void whisper_clamp_mask_kernel(
 
 using namespace sttfe;
 
+#ifdef STTFE_STAMPS
+extern "C" int sttfe_debug_set_stamp_buffer(void* dev_buf) {
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(dev_buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &p, sizeof(p)) == hipSuccess ? 0 : -4;
+}
+#endif
+
 extern "C" int sttfe_whisper_workspace_bytes(int batch, size_t* bytes) {
     if (batch < 0 || !bytes) return STTFE_E_INVALID_ARG;
-    *bytes = ((size_t)batch * sizeof(unsigned) + 255) / 256 * 256;
+    *bytes = (size_t)batch * wh::kKeysPerClip * sizeof(unsigned);
     return STTFE_OK;
 }
 
-// Clips per launch pair: kernel 1's output for a chunk (<= 96 x 1.5 MB) should still sit in the
-// 256 MiB Infinity Cache when kernel 2 re-reads it.
-static int g_whisper_chunk = 96;
-extern "C" int sttfe_set_whisper_chunk(int clips) {
-    if (clips < 1) return STTFE_E_INVALID_ARG;
-    g_whisper_chunk = clips;
+// Consecutive 48-frame tiles one workgroup of kernel 1 walks (tuning knob; 0 = default).
+static int g_whisper_tiles_per_block = 9;
+extern "C" int sttfe_set_whisper_tiles_per_block(int tiles) {
+    if (tiles < 0 || tiles > wh::kMaxTiles) return STTFE_E_INVALID_ARG;
+    g_whisper_tiles_per_block = tiles ? tiles : 9;
     return STTFE_OK;
 }
 
@@ -290,34 +504,28 @@ extern "C" int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, co
         return STTFE_E_INVALID_ARG;
     if (batch == 0) return STTFE_OK;
     if (!pcm || !offsets || !lengths || !dev_tables || !out || !workspace) return STTFE_E_INVALID_ARG;
-    if ((size_t)kHop * (size_t)n_frames > (size_t)kMaxSamples) return STTFE_E_UNSUPPORTED;
+    if ((size_t)wh::kHop * (size_t)n_frames > (size_t)wh::kMaxSamples || batch > 65535) return STTFE_E_UNSUPPORTED;
     size_t need = 0;
     sttfe_whisper_workspace_bytes(batch, &need);
     if (workspace_bytes < need) return STTFE_E_WORKSPACE;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     unsigned* keys = reinterpret_cast<unsigned*>(workspace);
     (void)hipGetLastError();      // drop any stale error left by earlier, unrelated HIP calls of this thread
-    if (hip_failed(hipMemsetAsync(keys, 0, need, stream), "hipMemsetAsync(max keys)")) return STTFE_E_LAUNCH;
+    if (hip_failed(hipMemsetAsync(keys, 0, need, stream), "hipMemsetAsync(keys)")) return STTFE_E_LAUNCH;
 
-    const int n_tiles = (n_frames + kTileFrames - 1) / kTileFrames;
-    const int tiles_per_block = 4;
+    const int n_tiles = (n_frames + wh::kTileFrames - 1) / wh::kTileFrames;
+    const int tiles_per_block = g_whisper_tiles_per_block;
     const int blocks_x = (n_tiles + tiles_per_block - 1) / tiles_per_block;
     const auto* tab = reinterpret_cast<const WhisperTablesHeader*>(dev_tables);
-    for (int c0 = 0; c0 < batch; c0 += g_whisper_chunk) {
-        const int nc = (batch - c0 < g_whisper_chunk) ? batch - c0 : g_whisper_chunk;
-        {
-            ScopedTiming t(kTimeWhisperStftMel, stream);
-            hipLaunchKernelGGL(whisper_stft_mel_kernel, dim3(blocks_x, nc), dim3(kThreads), 0, stream,
-                               pcm, offsets, lengths, c0, n_mels, n_frames, tab, out, keys, tiles_per_block);
-        }
-        const int total4 = n_mels * n_frames / 4;
-        int bx = (total4 + 255) / 256;
-        if (bx > 32) bx = 32;
-        {
-            ScopedTiming t(kTimeWhisperClamp, stream);
-            hipLaunchKernelGGL(whisper_clamp_mask_kernel, dim3(bx, nc), dim3(256), 0, stream, out, keys, c0,
-                               n_mels, n_frames, mask_tbl, n_masks);
-        }
+    {
+        ScopedTiming t(kTimeWhisperStftMel, stream);
+        hipLaunchKernelGGL(whisper_stft_mel_kernel, dim3(blocks_x, batch), dim3(wh::kThreads), 0, stream,
+                           pcm, offsets, lengths, n_mels, n_frames, tab, out, keys, mask_tbl, n_masks, tiles_per_block);
+    }
+    {
+        ScopedTiming t(kTimeWhisperClamp, stream);
+        hipLaunchKernelGGL(whisper_clamp_fill_kernel, dim3(n_tiles, batch), dim3(256), 0, stream, out, lengths, keys,
+                           n_mels, n_frames, mask_tbl, n_masks, tiles_per_block);
     }
     if (hip_failed(hipGetLastError(), "whisper kernel launch")) return STTFE_E_LAUNCH;
     return STTFE_OK;
