@@ -4,17 +4,24 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU.  A "step" = one pass of the hot path (sttfe_whisper_logmel: STFT + mel + log +
-per-clip clamp) over one batch of `--batch` synthetic 30 s clips that already sit in HBM.  Clips are
-sharded by rank (weak scaling: every rank processes its own batch; no collective on the data path).
-Rank 0 prints ONE JSON line.  value = audio-seconds processed by all ranks / max-over-ranks time.
+One process per GPU.  A "step" = one pass of the hot path over one batch of synthetic clips that already
+sit in HBM.  Clips are sharded by rank (weak scaling: every rank processes its own batch; no collective
+on the data path).  Rank 0 prints ONE JSON line.  value = audio-seconds processed by all ranks /
+max-over-ranks time.
 
-roofline: dominant kernel = whisper_stft_mel_kernel; achieved = algorithmic bytes per launch
-(2.88 MB per 80-mel 30 s clip: 1.92 MB PCM read once + 0.96 MB features written once, SURVEY.md
-section 8d, times the clips in one launch) / its average launch duration, measured with HIP events
+--workload selects the BASELINE.json configuration (default: the headline one):
+  whisper80         configs[0] shape at GPU batch: 1024 x 30 s clips @16 kHz -> (1024, 80, 3000)   [headline]
+  s2t               configs[1]: Speech2Text fbank + CMVN, 256 ragged 2-10 s clips, dynamic padding
+  resample_whisper  configs[2]: 48 kHz Common-Voice-length clips -> resample + normalise -> Whisper-80, batch 512
+  whisper128_aug    configs[3]: Whisper 128-mel + SpecAugment masks, Common-Voice-length clips, batch 1024
+
+roofline: dominant kernel of the workload; achieved = algorithmic bytes per launch (SURVEY.md section 8d:
+input PCM needed + output written, each once) / its average launch duration, measured with HIP events
 recorded on the launch stream inside libsttfe.so (sttfe_timing_*).  peak = 8 TB/s HBM3E.
-cpu_baseline: the reference's CPU extractor (HF WhisperFeatureExtractor, torch-CPU path) on a
-bounded sample of the same workload, rank 0, N = 1 only.
+traffic = HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x 2
++ WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md), when that file covers the workload.
+cpu_baseline: the reference's CPU extractor (HF, torch-CPU path) on a bounded sample of the same
+workload, rank 0, N = 1 only.
 """
 from __future__ import annotations
 
@@ -32,34 +39,58 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_SAMPLES = 480000
-CLIP_SECONDS = 30.0
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(n_mels: int, clips_np):
-    """Times the reference CPU extractor on `clips_np` (list of float32 arrays).  ~10-20 s of CPU work."""
+def cpu_baseline(workload: str, n_mels: int, clips_np):
+    """Times the reference CPU extractor on `clips_np` (list of float32 arrays @16 kHz).  ~10-20 s of CPU work."""
     cores = torch.get_num_threads()
+    s2t = workload == "s2t"
     try:
-        from transformers import WhisperFeatureExtractor
-        fe = WhisperFeatureExtractor(feature_size=n_mels)
-        fn = lambda: fe(clips_np, sampling_rate=16000, return_tensors="pt").input_features
+        if s2t:
+            from transformers import Speech2TextFeatureExtractor
+            fe = Speech2TextFeatureExtractor()
+            fn = lambda: fe(clips_np, sampling_rate=16000, return_tensors="pt", padding=True).input_features
+            what = "transformers.Speech2TextFeatureExtractor (NumPy path)"
+        else:
+            from transformers import WhisperFeatureExtractor
+            fe = WhisperFeatureExtractor(feature_size=n_mels)
+            fn = lambda: fe(clips_np, sampling_rate=16000, return_tensors="pt").input_features
+            what = "transformers.WhisperFeatureExtractor (torch-CPU path)"
         kind = "reference"
-        what = "transformers.WhisperFeatureExtractor (torch-CPU path)"
+        fn()                                              # warm-up
     except Exception:                                     # transformers missing on the box
-        from oracle.whisper import whisper_features_f32
-        fn = lambda: whisper_features_f32(clips_np, n_mels)
+        if s2t:
+            from oracle.kaldi import speech2text_features
+            fn = lambda: speech2text_features(clips_np)
+            what = "oracle.kaldi.speech2text_features"
+        else:
+            from oracle.whisper import whisper_features_f32
+            fn = lambda: whisper_features_f32(clips_np, n_mels)
+            what = "oracle.whisper.whisper_features_f32"
         kind = "port"
-        what = "oracle.whisper.whisper_features_f32"
-    fn()                                                  # warm-up
+        fn()
     reps, t_total = 0, 0.0
     while t_total < 10.0 and reps < 50:
         t0 = time.perf_counter()
         fn()
         t_total += time.perf_counter() - t0
         reps += 1
-    audio_s = len(clips_np) * CLIP_SECONDS * reps
+    audio_s = sum(len(c) for c in clips_np) / 16000.0 * reps
     return {"value": audio_s / t_total, "unit": "audio-s/s", "cores": cores, "kind": kind,
-            "sample": f"{len(clips_np)} x 30 s clips x {reps} passes of {what}"}
+            "sample": f"{len(clips_np)} clips ({audio_s / reps:.0f} audio-s) x {reps} passes of {what}"}
+
+
+def profile_traffic(workload: str, clips_per_launch: float):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (None if not covered)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        rec = json.load(open(path)).get(workload)
+        if rec and abs(rec["clips_per_launch"] - clips_per_launch) < 0.5:
+            return rec["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def main():
@@ -67,8 +98,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="clips per GPU per step")
-    ap.add_argument("--n-mels", type=int, default=80)
+    ap.add_argument("--workload", default="whisper80",
+                    choices=["whisper80", "s2t", "resample_whisper", "whisper128_aug"])
+    ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (0 = the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -89,21 +121,71 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     from speech_to_text_amd import _lib
-    from speech_to_text_amd.processors import HipWhisperFeatureExtractor
-    from speech_to_text_amd.synth import synth_batch_device
+    from speech_to_text_amd.augment import SpecAugmentSampler
+    from speech_to_text_amd.config import AugmentationConfig
+    from speech_to_text_amd.preprocess import GpuAudioPreprocessor
+    from speech_to_text_amd.processors import HipSpeech2TextFeatureExtractor, HipWhisperFeatureExtractor
+    from speech_to_text_amd.synth import common_voice_lengths, synth_batch_device
 
     L = _lib.lib()
-    fe = HipWhisperFeatureExtractor(args.n_mels, device=device)
-    B = args.batch
-    # clip-sharded corpus: rank r owns clips [r*B, (r+1)*B) (seeded per rank)
-    pcm2d = synth_batch_device(1000 + rank, B, N_SAMPLES, device)
-    pcm = pcm2d.reshape(-1)
-    offsets = (torch.arange(B, dtype=torch.int64) * N_SAMPLES).to(device)
-    lengths = torch.full((B,), N_SAMPLES, dtype=torch.int32, device=device)
-    out = torch.empty((B, args.n_mels, 3000), dtype=torch.float32, device=device)
+    wl = args.workload
+    seed = {"whisper80": 101, "s2t": 102, "resample_whisper": 103, "whisper128_aug": 104}[wl] * 1000 + rank
+    rng = np.random.default_rng(seed)
+    B = args.batch or {"whisper80": 1024, "s2t": 256, "resample_whisper": 512, "whisper128_aug": 1024}[wl]
+    n_mels = 128 if wl == "whisper128_aug" else 80
+    extra_kernels = []
 
-    def step():
-        fe.extract(pcm, offsets, lengths, out=out)
+    # ------- synthetic inputs resident in HBM (clip-sharded corpus: rank r owns its own B clips) -------
+    if wl == "whisper80":
+        lens = np.full(B, N_SAMPLES, dtype=np.int64)
+        sr = 16000
+    elif wl == "s2t":
+        lens = rng.integers(32000, 160001, size=B)
+        sr = 16000
+    elif wl == "resample_whisper":
+        lens = common_voice_lengths(rng, B) * 3                     # decoded PCM at 48 kHz
+        sr = 48000
+    else:
+        lens = common_voice_lengths(rng, B)
+        sr = 16000
+    n_max = (int(lens.max()) + 63) // 64 * 64
+    pcm2d = synth_batch_device(seed, B, n_max, device, sample_rate=sr)
+    pcm = pcm2d.reshape(-1)
+    offsets = (torch.arange(B, dtype=torch.int64) * n_max).to(device)
+    lengths = torch.tensor(lens, dtype=torch.int32, device=device)
+    host_lens = [int(v) for v in lens]
+    audio_seconds = float(lens.sum()) / sr
+
+    if wl in ("whisper80", "resample_whisper", "whisper128_aug"):
+        fe = HipWhisperFeatureExtractor(n_mels, device=device)
+        out = torch.empty((B, n_mels, 3000), dtype=torch.float32, device=device)
+        kernel, kname = "whisper_stft_mel", "whisper_stft_mel_kernel"
+        valid16 = np.minimum(lens // (3 if sr == 48000 else 1), N_SAMPLES)
+        bytes_per_launch = float(4 * valid16.sum() + 4 * n_mels * 3000 * B)
+        if wl == "whisper80":
+            step = lambda: fe.extract(pcm, offsets, lengths, out=out)
+        elif wl == "whisper128_aug":
+            sampler = SpecAugmentSampler(AugmentationConfig(enabled=True))
+            torch.manual_seed(104)
+            import random
+            random.seed(104)
+            table = sampler.mask_table([(n_mels, 3000)] * B).to(device)      # drawn once: RNG is host work
+            step = lambda: fe.extract(pcm, offsets, lengths, mask_table=table, out=out)
+        else:
+            pre = GpuAudioPreprocessor(normalize=True, trim_silence=False, min_duration=0.0, max_duration=1e9,
+                                       device=device)
+            extra_kernels = ["resample_peak", "normalize_trim"]
+
+            def step():
+                p = pre.run(pcm, offsets, lengths, host_lens, 1, 48000)
+                fe.extract(p.pcm, p.offsets, p.lengths, out=out)
+    else:
+        fe = HipSpeech2TextFeatureExtractor(device=device)
+        t_max = max(fe.num_frames(n) for n in host_lens)
+        kernel, kname = "kaldi_fbank", "kaldi_fbank_kernel"
+        extra_kernels = ["kaldi_cmvn"]
+        bytes_per_launch = float(4 * lens.sum() + (4 * 80 + 4) * t_max * B)
+        step = lambda: fe.extract(pcm, offsets, lengths, t_max)
 
     def barrier():
         if dist is not None:
@@ -123,23 +205,37 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        a = torch.tensor([audio_seconds], dtype=torch.float64, device=device)
+        dist.all_reduce(a, op=dist.ReduceOp.SUM)
+        audio_total = float(a.item())
+    else:
+        audio_total = audio_seconds
 
-    tot_ms, launches = ctypes.c_double(), ctypes.c_int()
-    _lib.check(L.sttfe_timing_query(b"whisper_stft_mel", ctypes.byref(tot_ms), ctypes.byref(launches)))
-    clamp_ms, clamp_n = ctypes.c_double(), ctypes.c_int()
-    _lib.check(L.sttfe_timing_query(b"whisper_clamp_mask", ctypes.byref(clamp_ms), ctypes.byref(clamp_n)))
+    def query(name):
+        ms, n = ctypes.c_double(), ctypes.c_int()
+        _lib.check(L.sttfe_timing_query(name.encode(), ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    tot_ms, launches = query(kernel)
+    others = {k: query(k) for k in (["whisper_clamp_mask"] if kernel == "whisper_stft_mel" else []) + extra_kernels}
     _lib.check(L.sttfe_timing_enable(0))
 
     if rank == 0:
-        bytes_per_clip = 4 * N_SAMPLES + 4 * args.n_mels * 3000
-        clips_per_launch = B * args.steps / max(launches.value, 1)
-        avg_ms = tot_ms.value / max(launches.value, 1)
-        achieved = bytes_per_clip * clips_per_launch / (avg_ms * 1e-3) / 1e9
-        audio_s = world * B * CLIP_SECONDS * args.steps
+        clips_per_launch = B * args.steps / max(launches, 1)
+        avg_ms = tot_ms / max(launches, 1)
+        achieved = bytes_per_launch * (clips_per_launch / B) / (avg_ms * 1e-3) / 1e9
+        names = {"whisper80": "log-mel audio-sec/sec (80-mel, 30 s clips)",
+                 "s2t": "Speech2Text fbank+CMVN audio-sec/sec (80-mel, 2-10 s clips)",
+                 "resample_whisper": "48->16 kHz resample + log-mel audio-sec/sec (80-mel, Common-Voice-length clips)",
+                 "whisper128_aug": "log-mel + SpecAugment audio-sec/sec (128-mel, Common-Voice-length clips)"}
+        shapes = {"whisper80": f"Whisper 80-mel log-mel, {B} x 30 s clips @16 kHz per GPU (BASELINE configs[0] shape "
+                               "at GPU batch; inputs resident in HBM)",
+                  "s2t": f"BASELINE configs[1]: Speech2Text fbank + utterance CMVN, {B} ragged 2-10 s clips, dynamic padding",
+                  "resample_whisper": f"BASELINE configs[2]: 48 kHz PCM -> resample + peak normalise -> Whisper 80-mel, {B} clips",
+                  "whisper128_aug": f"BASELINE configs[3]: Whisper 128-mel + SpecAugment masks, {B} clips"}
         result = {
-            "metric": "log-mel audio-sec/sec (80-mel, 30 s clips)" if args.n_mels == 80
-                      else f"log-mel audio-sec/sec ({args.n_mels}-mel, 30 s clips)",
-            "value": audio_s / elapsed,
+            "metric": names[wl],
+            "value": audio_total * args.steps / elapsed,
             "unit": "audio-s/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -150,20 +246,24 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"Whisper {args.n_mels}-mel log-mel, {B} x 30 s clips @16 kHz per GPU "
-                                   "(BASELINE configs[0] shape at GPU batch; inputs resident in HBM)",
-                       "clips_per_gpu": B, "n_mels": args.n_mels, "n_frames": 3000,
+            "config": {"workload": shapes[wl], "clips_per_gpu": B, "n_mels": n_mels,
                        "sharding": f"clip-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "whisper_stft_mel_kernel", "avg_launch_ms": avg_ms,
-                         "clips_per_launch": clips_per_launch, "launches": launches.value,
-                         "clamp_kernel_avg_ms": clamp_ms.value / max(clamp_n.value, 1),
-                         "whole_step_frac": bytes_per_clip * B * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": profile_traffic(wl, clips_per_launch),
+                         "kernel": kname, "avg_launch_ms": avg_ms, "clips_per_launch": clips_per_launch,
+                         "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "other_kernels_avg_ms": {k: (v[0] / max(v[1], 1)) for k, v in others.items()},
+                         "whole_step_frac": bytes_per_launch * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
         }
         if world == 1 and not args.no_cpu_baseline:
-            sample = [pcm2d[i].cpu().numpy() for i in range(32)]
-            result["cpu_baseline"] = cpu_baseline(args.n_mels, sample)
+            n_s = 32 if wl != "s2t" else 16
+            div = 3 if sr == 48000 else 1
+            sample = []
+            for i in range(min(n_s, B)):
+                c = pcm2d[i, :host_lens[i]].cpu().numpy()
+                sample.append(np.ascontiguousarray(c[::div]) if div > 1 else c)     # CPU side gets 16 kHz audio
+            result["cpu_baseline"] = cpu_baseline(wl, n_mels, sample)
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)

@@ -5,3 +5,10 @@ Host side of the drop-in for the feature-extraction path of Alexey511/speech_to_
 kernels behind the C-ABI library ``libsttfe.so`` (``include/sttfe.h``); there is no CPU fallback.
 """
 __version__ = "0.1.0"
+
+from .augment import SpecAugmentSampler  # noqa: F401
+from .config import AugmentationConfig, DataConfig  # noqa: F401
+from .data import AudioCollator, GpuFrontEnd  # noqa: F401
+from .preprocess import GpuAudioPreprocessor, PackedAudio, ResamplePlan  # noqa: F401
+from .processors import (BatchFeature, HipSpeech2TextFeatureExtractor, HipWhisperFeatureExtractor,  # noqa: F401
+                         TorchWhisperFeatureExtractor, pack_clips)

@@ -32,6 +32,7 @@
 //   recorded minimum is below max - 8 (otherwise it is already final and the workgroup exits).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/sttfe.h"
 #include "fft_core.h"
@@ -421,53 +422,103 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     }
 }
 
-// One workgroup per (tile, clip): fill padding tiles with the final constant, clamp computed tiles whose
-// minimum is below max - 8; SpecAugment masks -> 0.0 on everything it writes.
+// Clamp / fill pass.  grid.x = n_runs + kFillBlocks, grid.y = clips.
+//   x <  n_runs : the run of tiles one kernel-1 workgroup walked: re-read and clamp to (max - 8 + 4) / 4
+//                 only when the run's recorded minimum is below max - 8 (otherwise exit at once);
+//   x >= n_runs : fill role: mel rows x - n_runs, + kFillBlocks, ... of the clip's zero-padding region
+//                 [first padding frame, n_frames) get the final constant with full-row vector stores.
+// SpecAugment masks -> 0.0 on everything written.
 __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     float* __restrict__ out, const int32_t* __restrict__ lengths, const unsigned* __restrict__ keys,
-    int n_mels, int n_frames, const int32_t* __restrict__ mask_tbl, int n_masks, int tiles_per_block) {
+    int n_mels, int n_frames, const int32_t* __restrict__ mask_tbl, int n_masks, int tiles_per_block, int n_runs) {
     using namespace wh;
-    const int clip = blockIdx.y, tile = blockIdx.x;
+    const int kFillBlocks = gridDim.x - n_runs;
+    const int clip = blockIdx.y;
     int n_valid = lengths[clip];
     n_valid = n_valid < 0 ? 0 : (n_valid > kMaxSamples ? kMaxSamples : n_valid);
+    const int n_tiles = (n_frames + kTileFrames - 1) / kTileFrames;
+    const int first_pad_tile = min(n_tiles, (n_valid + kNfft / 2 + kHop * kTileFrames - 1) / (kHop * kTileFrames));
+    const int pad_frame = min(n_frames, first_pad_tile * kTileFrames);         // first frame of the constant region
     const unsigned kmax = keys[(size_t)clip * kKeysPerClip];
     const float lmax = kmax ? key_to_float(kmax) : -10.0f;        // no computed tile at all: log10(1e-10)
     const float floor_lg = lmax - 8.0f;
     const float floor_y = (floor_lg + 4.0f) * 0.25f;
-    const int t0 = tile * kTileFrames;
-    const int width = min(kTileFrames, n_frames - t0);
-    const bool padding = kHop * t0 - kNfft / 2 >= n_valid;
-    if (!padding) {
-        // minimum over the run of tiles one kernel-1 workgroup walked
-        const unsigned kmin = ~keys[(size_t)clip * kKeysPerClip + 1 + tile / tiles_per_block];
+    int f_begin, f_end, row0, row_step;
+    bool fill;
+    if ((int)blockIdx.x < n_runs) {
+        const int t_begin = blockIdx.x * tiles_per_block;
+        f_begin = t_begin * kTileFrames;
+        f_end = min(pad_frame, (t_begin + tiles_per_block) * kTileFrames);
+        if (f_begin >= f_end) return;
+        const unsigned kmin = ~keys[(size_t)clip * kKeysPerClip + 1 + blockIdx.x];
         if (key_to_float(kmin) >= floor_lg) return;               // nothing in this run is below the floor
+        fill = false;
+        row0 = 0;
+        row_step = 1;
+    } else {
+        f_begin = pad_frame;
+        f_end = n_frames;
+        if (f_begin >= f_end) return;
+        fill = true;
+        row0 = blockIdx.x - n_runs;
+        row_step = kFillBlocks;
     }
     const float pad_y = fmaxf((-10.0f + 4.0f) * 0.25f, floor_y);
-    const int32_t* __restrict__ clip_masks = mask_tbl ? mask_tbl + (size_t)clip * n_masks * 3 : nullptr;
-    const int nm = clip_masks ? n_masks : 0;
-    const uint64_t tmask = mask_bits(clip_masks, nm, STTFE_AXIS_TIME, t0, kTileFrames);
-    const uint64_t melmask_lo = mask_bits(clip_masks, nm, STTFE_AXIS_FREQ, 0, 64);
-    const uint64_t melmask_hi = mask_bits(clip_masks, nm, STTFE_AXIS_FREQ, 64, 64);
-    float* __restrict__ o = out + (size_t)clip * n_mels * n_frames + t0;
-    // rows are n_frames floats long with n_frames % 4 == 0 and t0 % 4 == 0: float4 accesses are aligned
-    const int quads = width >> 2;
-    for (int e = threadIdx.x; e < n_mels * quads; e += blockDim.x) {
-        const int mel = e / quads, q = e - mel * quads;
-        f32x4* ptr = reinterpret_cast<f32x4*>(o + (size_t)mel * n_frames + 4 * q);
-        const bool mmasked = ((mel < 64 ? melmask_lo >> mel : melmask_hi >> (mel - 64)) & 1ull);
-        f32x4 v, w;
-        if (padding) v = f32x4{pad_y, pad_y, pad_y, pad_y};
-        else v = *ptr;
-        bool changed = padding;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float y = fmaxf(v[c], floor_y);
-            // masked cells of a computed tile already hold 0.0 and must stay 0.0
-            if (mmasked || ((tmask >> (4 * q + c)) & 1ull)) y = 0.0f;
-            changed |= (y != v[c]);
-            w[c] = y;
+    const int32_t* __restrict__ cm = mask_tbl ? mask_tbl + (size_t)clip * n_masks * 3 : nullptr;
+    const int nm = cm ? n_masks : 0;
+    const uint64_t melmask_lo = mask_bits(cm, nm, STTFE_AXIS_FREQ, 0, 64);
+    const uint64_t melmask_hi = mask_bits(cm, nm, STTFE_AXIS_FREQ, 64, 64);
+    int ts[8], te[8], nt = 0;                                      // time-axis masks of the clip
+    for (int i = 0; i < nm; ++i)
+        if (cm[3 * i] == STTFE_AXIS_TIME && cm[3 * i + 2] > cm[3 * i + 1]) {
+            ts[nt] = cm[3 * i + 1];
+            te[nt] = cm[3 * i + 2];
+            ++nt;
         }
-        if (changed) *ptr = w;
+    float* __restrict__ o = out + (size_t)clip * n_mels * n_frames;
+    // rows are n_frames floats long, n_frames % 4 == 0, f_begin % 4 == 0 (tile starts): float4 accesses are aligned
+    const int quads = (f_end - f_begin) >> 2;
+    if (fill) {
+        // constant rows with plain vector stores, then the few time-masked columns are zeroed
+        for (int mel = row0; mel < n_mels; mel += row_step) {
+            const bool mmasked = ((mel < 64 ? melmask_lo >> mel : melmask_hi >> (mel - 64)) & 1ull);
+            const float c = mmasked ? 0.0f : pad_y;
+            const f32x4 c4 = {c, c, c, c};
+            f32x4* rowp = reinterpret_cast<f32x4*>(o + (size_t)mel * n_frames + f_begin);
+            for (int q = threadIdx.x; q < quads; q += blockDim.x) rowp[q] = c4;
+        }
+        if (nt == 0) return;
+        __syncthreads();
+        for (int i = 0; i < nt; ++i) {
+            const int a = max(ts[i], f_begin), w = min(te[i], f_end) - a;
+            if (w <= 0) continue;
+            const int rows = (n_mels - row0 + row_step - 1) / row_step;
+            for (int e = threadIdx.x; e < rows * w; e += blockDim.x) {
+                const int r = e / w, c = e - r * w;
+                o[(size_t)(row0 + r * row_step) * n_frames + a + c] = 0.0f;
+            }
+        }
+        return;
+    }
+    for (int mel = row0; mel < n_mels; mel += row_step) {
+        const bool mmasked = ((mel < 64 ? melmask_lo >> mel : melmask_hi >> (mel - 64)) & 1ull);
+        f32x4* rowp = reinterpret_cast<f32x4*>(o + (size_t)mel * n_frames + f_begin);
+        for (int q = threadIdx.x; q < quads; q += blockDim.x) {
+            const f32x4 v = rowp[q];
+            f32x4 w;
+            bool changed = false;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float y = fmaxf(v[c], floor_y);
+                const int fr = f_begin + 4 * q + c;
+                bool masked = mmasked;                             // masked cells of a computed tile already hold 0.0
+                for (int i = 0; i < nt; ++i) masked |= (fr >= ts[i] && fr < te[i]);
+                if (masked) y = 0.0f;
+                changed |= (y != v[c]);
+                w[c] = y;
+            }
+            if (changed) rowp[q] = w;
+        }
     }
 }
 
@@ -524,8 +575,13 @@ extern "C" int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, co
     }
     {
         ScopedTiming t(kTimeWhisperClamp, stream);
-        hipLaunchKernelGGL(whisper_clamp_fill_kernel, dim3(n_tiles, batch), dim3(256), 0, stream, out, lengths, keys,
-                           n_mels, n_frames, mask_tbl, n_masks, tiles_per_block);
+        static const int fill_blocks = [] {
+            const char* e = getenv("STTFE_FILL_BLOCKS");          // tuning knob (default 8)
+            const int v = e ? atoi(e) : 8;
+            return v < 1 ? 1 : (v > 128 ? 128 : v);
+        }();
+        hipLaunchKernelGGL(whisper_clamp_fill_kernel, dim3(blocks_x + fill_blocks, batch), dim3(256), 0, stream, out,
+                           lengths, keys, n_mels, n_frames, mask_tbl, n_masks, tiles_per_block, blocks_x);
     }
     if (hip_failed(hipGetLastError(), "whisper kernel launch")) return STTFE_E_LAUNCH;
     return STTFE_OK;
