@@ -155,7 +155,7 @@ int sttfe_normalize_trim(float* pcm, int64_t* offsets, int32_t* lengths, int bat
                          int normalize, int trim, float silence_threshold,
                          void* workspace, size_t workspace_bytes, void* stream);
 
-/* Consecutive 72-frame tiles one workgroup of the STFT kernel walks (default 6; 0 restores it).
+/* Consecutive 48-frame tiles one workgroup of the STFT kernel walks (0 = automatic, the default: 21 for batches that fill the chip, down to 3 for small ones).
  * Tuning knob, no counterpart in the reference. */
 int sttfe_set_whisper_tiles_per_block(int tiles);
 

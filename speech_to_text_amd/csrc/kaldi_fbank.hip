@@ -81,6 +81,9 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     const int tile_begin = blockIdx.x * tiles_per_block;
     const int tile_end = min(tile_begin + tiles_per_block, n_tiles);
     if (tile_begin >= tile_end) return;
+    // pad cells of the panel rows are read by zero-weight MFMA steps and must be finite
+    for (int i = tid; i < kLdsBytes / 4; i += kThreads) panel[i] = 0.f;
+    __syncthreads();
 
     const float* __restrict__ afrag = reinterpret_cast<const float*>(tab + 1);
     const MelPlan& plan = tab->plan;

@@ -105,7 +105,7 @@ void build_mel_plan(const std::vector<float>& dense, int n_mels, int n_bins, flo
                 afrag.push_back(v);
             }
     }
-    // Longest-processing-time assignment of (mel tile, frame tile) units to the waves.
+    // Longest-processing-time assignment of (mel tile, frame tile) units to the 8 waves.
     struct Unit { int mt, ft, cost; };
     std::vector<Unit> units;
     for (int ft = 0; ft < n_ftiles; ++ft)
@@ -116,8 +116,7 @@ void build_mel_plan(const std::vector<float>& dense, int n_mels, int n_bins, flo
         int best = 0;
         for (int w = 1; w < n_waves; ++w)
             if (load[w] < load[best]) best = w;
-        // at most 8 mel tiles x 5 frame tiles = 40 units over 12 waves (or 16 over 4): <= kMaxUnitsPerWave each
-        if (plan.wave_nunits[best] >= kMaxUnitsPerWave) continue;
+        // n_mtiles * kFrameTiles = 24 units over 8 waves: LPT never needs more than kMaxUnitsPerWave
         plan.wave_units[best][plan.wave_nunits[best]++] = u.mt | (u.ft << 8);
         load[best] += u.cost;
     }
@@ -143,7 +142,7 @@ static int whisper_tables(int n_mels, std::vector<unsigned char>& blob) {
     std::memset(&h, 0, sizeof(h));
     // 0.25 = the 1/4 of the two-real-frames-in-one-complex-FFT separation, folded into the bank
     // (a power of two: bit-identical to scaling the power spectrum itself).
-    build_mel_plan(dense, n_mels, 201, 0.25f, kWavesPerBlock, kFrameTiles, 4, h.plan, afrag);   // 12 waves x 5 frame tiles
+    build_mel_plan(dense, n_mels, 201, 0.25f, 4, kFrameTiles, 4, h.plan, afrag);   // 4 waves x 3 frame tiles
     h.magic = kWhisperMagic;
     h.n_mels = n_mels;
     h.afrag_floats = (int32_t)afrag.size();

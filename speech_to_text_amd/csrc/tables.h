@@ -6,8 +6,8 @@ namespace sttfe {
 
 constexpr int kMaxMelTiles = 8;          // 128 mel bins / 16 rows per MFMA tile
 constexpr int kMaxUnitsPerWave = 8;
-constexpr int kWavesPerBlock = 12;
-constexpr int kFrameTiles = 5;           // Whisper: 72 frames per workgroup tile = 4.5 MFMA tiles of 16 columns
+constexpr int kWavesPerBlock = 8;
+constexpr int kFrameTiles = 3;           // 48 frames per block iteration / 16 columns per MFMA tile
 
 constexpr uint32_t kWhisperMagic = 0x57484d31u;   // "WHM1"
 constexpr uint32_t kKaldiMagic = 0x4b414c31u;     // "KAL1"

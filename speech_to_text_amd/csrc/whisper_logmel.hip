@@ -42,29 +42,27 @@
 namespace sttfe {
 
 namespace wh {
-constexpr int kThreads = 768;
-constexpr int kWaves = 12;
-constexpr int kTileFrames = 72;                // 4 full MFMA frame tiles + one half tile
-constexpr int kFrameTilesPerTile = 5;
-constexpr int kFramesPerWave = 6;             // one pass of 3 frame pairs per tile
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int kTileFrames = 48;
+constexpr int kFramesPerWave = 12;            // two passes of 3 pairs
 constexpr int kHop = 160;
 constexpr int kNfft = 400;
 constexpr int kMaxSamples = 480000;           // 30 s at 16 kHz (HF:...whisper.py:91)
-constexpr int kMaxTiles = 42;                 // ceil(3000 / 72)
+constexpr int kMaxTiles = 63;                 // ceil(3000 / 48)
 constexpr int kKeysPerClip = 64;              // workspace: [0] = max key, [1 + r] = ~min key of tile run r
-constexpr int kRowStride = 21;                // float2 units, [k1][n2] rows of the exchange slab
-constexpr int kPairStride = 420;              // float2 units per frame pair
+constexpr int kRowStride = 21;                // float2 units, [k1][n2] rows
+constexpr int kPairStride = 420;              // float2 units per frame pair (== 4 mod 32)
+constexpr int kSlabFloats = 3 * kPairStride * 2;      // 2520 floats per wave
 constexpr int kPStride = 202;                 // floats per frame row of the power panel (== 10 mod 32)
-constexpr int kSlabFloats = 3 * kPairStride * 2 + 4;  // 2524 floats per wave
-static_assert(kSlabFloats >= 3 * kPairStride * 2 && kSlabFloats % 2 == 0, "exchange slab");
-static_assert((kSlabFloats - kFramesPerWave * kPStride) % 32 == 0, "panel rows keep one bank pattern across waves");
 static_assert(kFramesPerWave * kPStride <= kSlabFloats, "a wave's panel rows must fit inside its own slab");
+static_assert((kSlabFloats - kFramesPerWave * kPStride) % 32 == 0, "panel rows keep one bank pattern across waves");
 constexpr int kWinOff = kWaves * kSlabFloats;         // float offsets of the tables inside the LDS array
 constexpr int kTwOff = kWinOff + 400;
 constexpr int kAfragOff = kTwOff + 800;               // banded mel weights in MFMA A-operand order
-constexpr int kMaxAfragFloats = 4096;                 // 60 (80 mels) / 64 (128 mels) k-steps x 64 lanes
-constexpr int kDescOff = kAfragOff + kMaxAfragFloats; // per wave: 8 x {kstart, nsteps, aoff, mt | ft << 8}, then the unit counts
-constexpr int kLdsFloats = kDescOff + kWaves * kMaxUnitsPerWave * 4 + kWaves;   // 63.1 KB -> 2 workgroups per CU
+constexpr int kMaxAfragFloats = 4096;                 // 53 (80 mels) / 56 (128 mels) k-steps x 64 lanes
+constexpr int kDescOff = kAfragOff + kMaxAfragFloats;     // per wave: 8 x {kstart, nsteps, aoff, mt | ft << 8}, then the unit counts
+constexpr int kLdsFloats = kDescOff + kWaves * kMaxUnitsPerWave * 4 + kWaves;   // 62032 B -> 2 workgroups per CU
 }  // namespace wh
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -115,7 +113,10 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #define STAMP(i)
 #endif
 
-__global__ __launch_bounds__(wh::kThreads, 3) void whisper_stft_mel_kernel(
+#ifndef STTFE_WH_WAVES_PER_SIMD
+#define STTFE_WH_WAVES_PER_SIMD 2
+#endif
+__global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper_stft_mel_kernel(
     const float* __restrict__ pcm, const int64_t* __restrict__ offsets,
     const int32_t* __restrict__ lengths, int n_mels, int n_frames,
     const WhisperTablesHeader* __restrict__ tab, float* __restrict__ out,
@@ -171,10 +172,17 @@ __global__ __launch_bounds__(wh::kThreads, 3) void whisper_stft_mel_kernel(
     const int nu = __builtin_amdgcn_readfirstlane(
         reinterpret_cast<const int*>(smem + kDescOff)[4 * kWaves * kMaxUnitsPerWave + wave]);
     const cf* tw_col = reinterpret_cast<const cf*>(smem + kTwOff) + j;
-    const float* win = smem + kWinOff + j;
     const int partner = active ? (p * 20 + ((20 - j) % 20)) : lane;
-    float* my_rows = smem + wave * kSlabFloats;                     // exchange slab, later this wave's 6 panel rows
-    cf* slab = reinterpret_cast<cf*>(my_rows) + pa_ * kPairStride;
+    cf* slab = reinterpret_cast<cf*>(smem + wave * kSlabFloats) + pa_ * kPairStride;
+    float* my_rows = smem + wave * kSlabFloats;
+
+#ifdef STTFE_WIN_REGS
+    float win[20];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) win[i] = smem[kWinOff + 20 * i + j];
+#else
+    const float* win = smem + kWinOff + j;
+#endif
 
     // SpecAugment: mel-axis masks as two 64-bit words for the clip; time-axis masks per tile
     const int32_t* __restrict__ clip_masks = mask_tbl ? mask_tbl + (size_t)clip * n_masks * 3 : nullptr;
@@ -182,14 +190,19 @@ __global__ __launch_bounds__(wh::kThreads, 3) void whisper_stft_mel_kernel(
     const uint64_t melmask_lo = mask_bits(clip_masks, nm, STTFE_AXIS_FREQ, 0, 64);
     const uint64_t melmask_hi = mask_bits(clip_masks, nm, STTFE_AXIS_FREQ, 64, 64);
 
-    // 28 samples per lane: frame a = rows 0..19, frame b = rows 8..27 of x[base + 20 m]
-    auto load_tile = [&](int t0, float (&r)[28]) {
-        const int f0 = t0 + wave * kFramesPerWave;                 // first frame of this wave (wave-uniform)
+    // 28 samples per lane and pass: frame a = rows 0..19, frame b = rows 8..27 of x[base + 20 m]
+    auto load_pass = [&](int t0, int pass, float (&r)[28]) {
+        const int f0 = t0 + wave * kFramesPerWave + 6 * pass;          // first frame of the pass (wave-uniform)
         const int first = kHop * f0 - kNfft / 2;
         const int base = first + 2 * kHop * pa_ + j;
         if (first >= 0 && first + 5 * kHop + kNfft <= n_valid) {
+#ifdef ABL_NOLOAD
+#pragma unroll
+            for (int m = 0; m < 28; ++m) r[m] = (float)(base + m) * 1e-7f;
+#else
 #pragma unroll
             for (int m = 0; m < 28; ++m) r[m] = x[base + 20 * m];
+#endif
         } else {
 #pragma unroll
             for (int m = 0; m < 28; ++m) {
@@ -201,16 +214,87 @@ __global__ __launch_bounds__(wh::kThreads, 3) void whisper_stft_mel_kernel(
         }
     };
 
+    // one pass: window, 20 x 20 DFT through the slab, spectra separation -> 4 |A|^2, 4 |B|^2 (bins j + 20 k2)
+    auto fft_stage1 = [&](const float (&raw)[28]) {
+        cf v[20], y[20];
+#pragma unroll
+        for (int i = 0; i < 20; ++i) {
+#ifdef STTFE_WIN_REGS
+            const float w = win[i];
+#else
+#ifdef ABL_NOWIN
+            const float w = 0.5f + i;
+#else
+            const float w = win[20 * i];
+#endif
+#endif
+            v[i] = cf{raw[i] * w, raw[i + 8] * w};
+        }
+        // all twiddle reads are issued before the first slab write: the compiler cannot move an LDS read
+        // above an LDS write of the same array, and one read-wait-write round trip per row costs ~1k cycles
+        cf tw[20];
+#pragma unroll
+        for (int k1 = 1; k1 < 20; ++k1) tw[k1] = tw_col[20 * k1];
+        dft20(v, y);
+        if (active) {
+            slab[j] = y[0];
+#pragma unroll
+            for (int k1 = 1; k1 < 20; ++k1) slab[k1 * kRowStride + j] = cmul(y[k1], tw[k1]);
+        }
+        wave_lds_sync();
+    };
+    auto fft_stage2 = [&](float (&pa)[11], float (&pb)[11]) {
+        cf v[20], y[20];
+#pragma unroll
+        for (int n2 = 0; n2 < 20; ++n2) v[n2] = slab[j * kRowStride + n2];
+        wave_lds_sync();      // the next writes to the slab (next pass / panel rows) come after these reads
+        dft20(v, y);          // y[k2] = Z[j + 20 k2]
+#pragma unroll
+        for (int k2 = 0; k2 < 10; ++k2) {
+            float qr = __shfl(y[19 - k2].x, partner, 64);
+            float qi = __shfl(y[19 - k2].y, partner, 64);
+            if (j == 0) {                                         // own Z[400 - 20 k2]
+                qr = (k2 == 0) ? y[0].x : y[20 - k2].x;
+                qi = (k2 == 0) ? y[0].y : y[20 - k2].y;
+            }
+            const float sr = y[k2].x + qr, dr = y[k2].x - qr;
+            const float si = y[k2].y + qi, di = y[k2].y - qi;
+            pa[k2] = sr * sr + di * di;                           // 4 |A[k]|^2
+            pb[k2] = si * si + dr * dr;                           // 4 |B[k]|^2
+        }
+        pa[10] = 4.0f * y[10].x * y[10].x;                        // bin 200 (lane j == 0 only)
+        pb[10] = 4.0f * y[10].y * y[10].y;
+    };
+
+    auto store_rows = [&](int pass, const float (&pa)[11], const float (&pb)[11]) {
+        if (!active) return;
+        float* row = my_rows + (6 * pass + 2 * p) * kPStride + j;
+#pragma unroll
+        for (int k2 = 0; k2 < 10; ++k2) {
+            row[20 * k2] = pa[k2];
+            row[kPStride + 20 * k2] = pb[k2];
+        }
+        if (j == 0) {
+            row[200] = pa[10];
+            row[kPStride + 200] = pb[10];
+        }
+    };
+
+#ifdef EXP_DEPHASE
+    if ((blockIdx.x + blockIdx.y) & 1) {
+        for (int i = 0; i < EXP_DEPHASE; ++i) __builtin_amdgcn_s_sleep(127);     // ~127 * 64 cycles each
+    }
+#endif
+    float run_max = -3.0e38f, run_min = 3.0e38f;
     // LDS float offset of this lane's B-operand row (frame ft * 16 + (lane & 15), k = lane >> 4) per frame tile
     auto b_row = [&](int ft) {
-        const int fl = min(ft * 16 + (lane & 15), kTileFrames - 1), fw = fl / kFramesPerWave;     // last frame tile is half empty
+        const int fl = ft * 16 + (lane & 15), fw = fl / kFramesPerWave;
         return fw * kSlabFloats + (fl - fw * kFramesPerWave) * kPStride + (lane >> 4);
     };
-    const int brow0 = b_row(0), brow1 = b_row(1), brow2 = b_row(2), brow3 = b_row(3), brow4 = b_row(4);
-
-    float run_max = -3.0e38f, run_min = 3.0e38f;
-    float raw[28];
-    load_tile(tile_begin * kTileFrames, raw);
+    const int brow0 = b_row(0), brow1 = b_row(1), brow2 = b_row(2);
+    float raw0[28], raw1[28];                      // the two passes of the NEXT tile, loaded a whole tile ahead
+    load_pass(tile_begin * kTileFrames, 0, raw0);
+    load_pass(tile_begin * kTileFrames, 1, raw1);
 #ifdef STTFE_STAMPS
     unsigned long long stamp_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
@@ -218,68 +302,28 @@ __global__ __launch_bounds__(wh::kThreads, 3) void whisper_stft_mel_kernel(
 
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const int t0 = tile * kTileFrames;
-        {
-            // ---------------- stage 1: window, 20-point DFT over n1, twiddle ---------------------------
-            cf v[20], y[20];
-#pragma unroll
-            for (int i = 0; i < 20; ++i) {
-                const float w = win[20 * i];
-                v[i] = cf{raw[i] * w, raw[i + 8] * w};
-            }
-            // twiddle reads are issued before the first slab write: the compiler cannot move an LDS read
-            // above an LDS write of the same array, and a read-wait-write round trip per row costs ~1k cycles
-            dft20(v, y);
-            {
-                cf tw[20];
-#pragma unroll
-                for (int k1 = 1; k1 < 20; ++k1) tw[k1] = tw_col[20 * k1];
-#pragma unroll
-                for (int k1 = 1; k1 < 20; ++k1) y[k1] = cmul(y[k1], tw[k1]);
-            }
-            STAMP(0);
-            // ---------------- transpose through the wave-private slab ---------------------------------
-            if (active) {
-#pragma unroll
-                for (int k1 = 0; k1 < 20; ++k1) slab[k1 * kRowStride + j] = y[k1];
-            }
-            wave_lds_sync();
-#pragma unroll
-            for (int n2 = 0; n2 < 20; ++n2) v[n2] = slab[j * kRowStride + n2];
-            wave_lds_sync();      // the panel rows written below alias the slab
-            STAMP(1);
-            // ---------------- stage 2: 20-point DFT over n2, separate the two real spectra ------------
-            dft20(v, y);          // y[k2] = Z[j + 20 k2]
-            float* row = my_rows + 2 * pa_ * kPStride + j;
-#pragma unroll
-            for (int k2 = 0; k2 < 10; ++k2) {
-                float qr = __shfl(y[19 - k2].x, partner, 64);
-                float qi = __shfl(y[19 - k2].y, partner, 64);
-                if (j == 0) {                                         // own Z[400 - 20 k2]
-                    qr = (k2 == 0) ? y[0].x : y[20 - k2].x;
-                    qi = (k2 == 0) ? y[0].y : y[20 - k2].y;
-                }
-                const float sr = y[k2].x + qr, dr = y[k2].x - qr;
-                const float si = y[k2].y + qi, di = y[k2].y - qi;
-                if (active) {
-                    row[20 * k2] = sr * sr + di * di;                 // 4 |A[k]|^2 -> this wave's panel rows
-                    row[kPStride + 20 * k2] = si * si + dr * dr;      // 4 |B[k]|^2
-                }
-            }
-            if (active && j == 0) {                                   // bin 200
-                row[200] = 4.0f * y[10].x * y[10].x;
-                row[kPStride + 200] = 4.0f * y[10].y * y[10].y;
-            }
-        }
+        float pa0[11], pb0[11], pa1[11], pb1[11];
+        const bool more = tile + 1 < tile_end;
+
+        fft_stage1(raw0);
+        STAMP(0);
+        if (more) load_pass(t0 + kTileFrames, 0, raw0);
+        fft_stage2(pa0, pb0);
         STAMP(2);
-        // next tile's PCM: issued here (few live registers from now on), lands during the MFMA phase
-        if (tile + 1 < tile_end) load_tile(t0 + kTileFrames, raw);
+        fft_stage1(raw1);
+        STAMP(3);
+        if (more) load_pass(t0 + kTileFrames, 1, raw1);
+        fft_stage2(pa1, pb1);
+        STAMP(4);
+
+        store_rows(0, pa0, pb0);
+        store_rows(1, pa1, pb1);
         STAMP(5);
         __syncthreads();                                           // panel complete
         STAMP(6);
 
         // ---------------- banded mel projection on the matrix cores + log epilogue --------------
-        const uint64_t tmask_lo = mask_bits(clip_masks, nm, STTFE_AXIS_TIME, t0, 64);
-        const uint64_t tmask_hi = mask_bits(clip_masks, nm, STTFE_AXIS_TIME, t0 + 64, kTileFrames - 64);
+        const uint64_t tmask = mask_bits(clip_masks, nm, STTFE_AXIS_TIME, t0, kTileFrames);
         int4v d = desc[0];                                          // {kstart, nsteps, aoff, mt | ft << 8}
         for (int u = 0; u < nu; ++u) {
             const int ks = __builtin_amdgcn_readfirstlane(d.x);
@@ -289,7 +333,7 @@ __global__ __launch_bounds__(wh::kThreads, 3) void whisper_stft_mel_kernel(
             d = desc[min(u + 1, kMaxUnitsPerWave - 1)];             // next unit's descriptor lands during this one
             const int mt = code & 0xff, ft = code >> 8;
             const float* a_ptr = afrag + ao + lane;
-            const float* b_ptr = smem + (ft == 0 ? brow0 : ft == 1 ? brow1 : ft == 2 ? brow2 : ft == 3 ? brow3 : brow4) + ks;
+            const float* b_ptr = smem + (ft == 0 ? brow0 : (ft == 1 ? brow1 : brow2)) + ks;
             // two interleaved accumulation chains hide the 40-cycle dependent latency of the 16x16x4 MFMA;
             // the operands of the next four steps are read while the current four multiply
             f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
@@ -329,8 +373,11 @@ __global__ __launch_bounds__(wh::kThreads, 3) void whisper_stft_mel_kernel(
             const unsigned o0 = (unsigned)(mel0 * n_frames + t0 + fl);
             float yv[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) yv[r] = __log2f(fmaxf(acc[r], 1e-10f)) * 0.30102999566398120f;
-            const bool whole = (mt * 16 + 16 <= n_mels) && (t0 + ft * 16 + 16 <= n_frames) && (ft * 16 + 16 <= kTileFrames);    // wave-uniform
+            for (int r = 0; r < 4; ++r) {
+                const float lg = __log2f(fmaxf(acc[r], 1e-10f)) * 0.30102999566398120f;
+                yv[r] = lg;
+            }
+            const bool whole = (mt * 16 + 16 <= n_mels) && (t0 + ft * 16 + 16 <= n_frames);    // wave-uniform
             if (whole && nm == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -339,11 +386,11 @@ __global__ __launch_bounds__(wh::kThreads, 3) void whisper_stft_mel_kernel(
                     out_clip[o0 + (unsigned)(r * n_frames)] = (yv[r] + 4.0f) * 0.25f;
                 }
             } else {
-                const bool tmasked = ((fl < 64 ? tmask_lo >> fl : tmask_hi >> (fl - 64)) & 1ull);
+                const bool tmasked = (tmask >> fl) & 1ull;
                 const unsigned mbits = (unsigned)((mel0 < 64 ? melmask_lo >> mel0 : melmask_hi >> (mel0 - 64)) & 15ull);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (mel0 + r < n_mels && t0 + fl < n_frames && fl < kTileFrames) {
+                    if (mel0 + r < n_mels && t0 + fl < n_frames) {
                         run_max = fmaxf(run_max, yv[r]);
                         run_min = fminf(run_min, yv[r]);
                         out_clip[o0 + (unsigned)(r * n_frames)] =
@@ -351,7 +398,7 @@ __global__ __launch_bounds__(wh::kThreads, 3) void whisper_stft_mel_kernel(
                     }
                 }
             }
-            STAMP(3);
+            STAMP(1);
         }
         STAMP(7);
         __syncthreads();      // panel reads done before the next tile's slab writes
@@ -492,11 +539,12 @@ extern "C" int sttfe_whisper_workspace_bytes(int batch, size_t* bytes) {
     return STTFE_OK;
 }
 
-// Consecutive 48-frame tiles one workgroup of kernel 1 walks (tuning knob; 0 = default).
-static int g_whisper_tiles_per_block = 6;
+// Consecutive 48-frame tiles one workgroup of kernel 1 walks (tuning knob; 0 = automatic: long runs
+// when the batch alone fills the chip, shorter ones for small batches).
+static int g_whisper_tiles_per_block = 0;
 extern "C" int sttfe_set_whisper_tiles_per_block(int tiles) {
     if (tiles < 0 || tiles > wh::kMaxTiles) return STTFE_E_INVALID_ARG;
-    g_whisper_tiles_per_block = tiles ? tiles : 6;
+    g_whisper_tiles_per_block = tiles;
     return STTFE_OK;
 }
 
@@ -518,7 +566,17 @@ extern "C" int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, co
     if (hip_failed(hipMemsetAsync(keys, 0, need, stream), "hipMemsetAsync(keys)")) return STTFE_E_LAUNCH;
 
     const int n_tiles = (n_frames + wh::kTileFrames - 1) / wh::kTileFrames;
-    const int tiles_per_block = g_whisper_tiles_per_block;
+    int tiles_per_block = g_whisper_tiles_per_block;
+    if (tiles_per_block == 0) {
+        // two 4-wave workgroups per CU, 256 CUs: aim for >= 2 rounds of workgroups, runs as long as possible
+        const int choices[5] = {21, 9, 7, 5, 3};
+        tiles_per_block = 3;
+        for (int c : choices)
+            if ((long)batch * ((n_tiles + c - 1) / c) >= 1024) {
+                tiles_per_block = c;
+                break;
+            }
+    }
     const int blocks_x = (n_tiles + tiles_per_block - 1) / tiles_per_block;
     const auto* tab = reinterpret_cast<const WhisperTablesHeader*>(dev_tables);
     {

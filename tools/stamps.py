@@ -11,8 +11,8 @@ dev = torch.device("cuda:0")
 L = _lib.lib()
 tpb = int(os.environ.get("AB_TPB", "9"))
 L.sttfe_set_whisper_tiles_per_block(tpb)
-nblk = (42 + tpb - 1) // tpb * B
-buf = torch.zeros(nblk * 12 * 10, dtype=torch.int64, device=dev)
+nblk = (63 + tpb - 1) // tpb * B
+buf = torch.zeros(nblk * 4 * 10, dtype=torch.int64, device=dev)
 L.sttfe_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
 assert L.sttfe_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr())) == 0
 fe = HipWhisperFeatureExtractor(80, device=dev)
@@ -23,10 +23,9 @@ out = torch.empty((B, 80, 3000), dtype=torch.float32, device=dev)
 for _ in range(3):
     fe.extract(pcm, off, ln, out=out)
 torch.cuda.synchronize()
-s = buf.view(nblk, 12, 10).double()
+s = buf.view(nblk, 4, 10).double()
 tot = s.sum(dim=2).mean()
-names = ["stage1", "exchange", "stage2+power", "epilogues", "-", "panel rows", "barrier B2", "(loop exit)", "barrier B3", "mfma loops"]
-names_old = ["stage1(p0)", "epilogue+min", "stage2(p0)", "stage1(p1)", "loads+stage2(p1)", "panel rows", "barrier B2", "(loop exit)", "barrier B3", "mfma loops"]
+names = ["stage1(p0)", "epilogue+min", "stage2(p0)", "stage1(p1)", "loads+stage2(p1)", "panel rows", "barrier B2", "(loop exit)", "barrier B3", "mfma loops"]
 print(f"mean cycles per wave {tot:.0f} ({tot/tpb:.0f} per tile)")
 for i, n in enumerate(names[:10]):
     print(f"  {n:18s} {s[:, :, i].mean()/tpb:8.0f} cycles/tile  {100*s[:, :, i].mean()/tot:5.1f}%")
