@@ -31,22 +31,29 @@
 namespace sttfe {
 
 namespace kaldi {
-constexpr int kThreads = 256;
-constexpr int kWaves = 4;
-constexpr int kTileFrames = 32;
+constexpr int kThreads = 512;
+constexpr int kWaves = 8;
+constexpr int kTileFrames = 64;            // 8 waves x 8 frames = 4 MFMA frame tiles
 constexpr int kFramesPerWave = 8;
 constexpr int kHop = 160;
 constexpr int kFrame = 400;
 constexpr int kRowStride = 33;             // float2 units, [k1][n2] rows
 constexpr int kPairStride = 528;           // float2 units per pair (== 16 mod 32)
-constexpr int kSlabPerWave = 4 * kPairStride;
+constexpr int kSlabFloats = 4 * kPairStride * 2 + 16; // 4240 floats per wave
 constexpr int kPStride = 258;              // floats per frame row of the power panel (== 2 mod 32)
-constexpr int kLdsBytes = kWaves * kSlabPerWave * 8;     // 67584 B -> 2 workgroups per CU
-static_assert(kTileFrames * kPStride * 4 <= kLdsBytes, "power panel must fit inside the FFT slabs");
+static_assert(kFramesPerWave * kPStride <= kSlabFloats, "a wave's panel rows must fit inside its own slab");
+static_assert((kSlabFloats - kFramesPerWave * kPStride) % 32 == 0, "panel rows keep one bank pattern across waves");
+constexpr int kWinOff = kWaves * kSlabFloats;          // float offsets of the tables inside the LDS array
+constexpr int kTwOff = kWinOff + 400;
+constexpr int kAfragOff = kTwOff + 1024;
+constexpr int kMaxAfragFloats = 4992;      // 78 k-steps x 64 lanes (80 mels need 76)
+constexpr int kDescOff = kAfragOff + kMaxAfragFloats;  // per wave: 8 x {kstart, nsteps, aoff, mt | ft << 8}, then the unit counts
+constexpr int kLdsFloats = kDescOff + kWaves * kMaxUnitsPerWave * 4 + kWaves;     // ~161 KB: one workgroup per CU
 constexpr float kMelFloor = 1.1920928955078125e-07f;
 }  // namespace kaldi
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int int4k __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void wave_lds_sync2() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -60,15 +67,17 @@ __device__ __forceinline__ int kaldi_num_frames(int n, int max_frames, int t_max
     return t > t_max ? t_max : t;
 }
 
+// One 512-thread workgroup (8 waves, <= 256 VGPRs, ~161 KB LDS -> one per CU) walks a run of consecutive
+// 64-frame tiles of one clip.  Window, twiddles, the banded mel weights (MFMA B-operand order) and the
+// per-wave unit plan are staged in LDS once per run; the CMVN sums of the run are kept in registers
+// (float64) and reach memory with one atomic per mel bin and wave at the end of the run.
 __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     const float* __restrict__ pcm, const int64_t* __restrict__ offsets,
     const int32_t* __restrict__ lengths, int n_mels, int t_max, int max_frames,
     const KaldiTablesHeader* __restrict__ tab, float* __restrict__ out, double* __restrict__ stats,
     int tiles_per_block) {
     using namespace kaldi;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsBytes];
-    cf* slab_all = reinterpret_cast<cf*>(smem);
-    float* panel = reinterpret_cast<float*>(smem);
+    __shared__ __attribute__((aligned(16))) float smem[kLdsFloats];
 
     const int clip = blockIdx.y;
     const int tid = threadIdx.x;
@@ -81,14 +90,38 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     const int tile_begin = blockIdx.x * tiles_per_block;
     const int tile_end = min(tile_begin + tiles_per_block, n_tiles);
     if (tile_begin >= tile_end) return;
-    // pad cells of the panel rows are read by zero-weight MFMA steps and must be finite
-    for (int i = tid; i < kLdsBytes / 4; i += kThreads) panel[i] = 0.f;
+
+    // zero the slabs once (pad cells of the panel rows are read by zero-weight MFMA steps and must be
+    // finite), stage the tables
+    for (int i = tid; i < kWinOff; i += kThreads) smem[i] = 0.f;
+    for (int i = tid; i < 400; i += kThreads) smem[kWinOff + i] = tab->window[i];
+    for (int i = tid; i < 1024; i += kThreads) smem[kTwOff + i] = tab->twiddle[i];
+    {
+        const float* __restrict__ afrag_g = reinterpret_cast<const float*>(tab + 1);
+        const int na = min(tab->afrag_floats, kMaxAfragFloats);
+        for (int i = tid; i < na; i += kThreads) smem[kAfragOff + i] = afrag_g[i];
+        int* desc = reinterpret_cast<int*>(smem + kDescOff);
+        if (tid < kWaves * kMaxUnitsPerWave) {
+            const int w = tid / kMaxUnitsPerWave, u = tid - w * kMaxUnitsPerWave;
+            const int code = tab->plan.wave_units[w][u], mt = code & 0xff;
+            const bool ok = u < tab->plan.wave_nunits[w];
+            desc[4 * tid + 0] = ok ? tab->plan.kstart[mt] : 0;
+            desc[4 * tid + 1] = ok ? tab->plan.nsteps[mt] : 0;
+            desc[4 * tid + 2] = ok ? tab->plan.aoff[mt] : 0;
+            desc[4 * tid + 3] = code;
+        }
+        if (tid < kWaves) desc[4 * kWaves * kMaxUnitsPerWave + tid] = tab->plan.wave_nunits[tid];
+    }
     __syncthreads();
 
-    const float* __restrict__ afrag = reinterpret_cast<const float*>(tab + 1);
-    const MelPlan& plan = tab->plan;
-    const cf* __restrict__ tw_tab = reinterpret_cast<const cf*>(tab->twiddle);
-    cf* slab_w = slab_all + wave * kSlabPerWave;
+    const float* wfrag = smem + kAfragOff;
+    const int4k* desc = reinterpret_cast<const int4k*>(smem + kDescOff) + wave * kMaxUnitsPerWave;
+    const int nu = __builtin_amdgcn_readfirstlane(
+        reinterpret_cast<const int*>(smem + kDescOff)[4 * kWaves * kMaxUnitsPerWave + wave]);
+    const cf* tw_tab = reinterpret_cast<const cf*>(smem + kTwOff);
+    const float* win = smem + kWinOff;
+    float* my_rows = smem + wave * kSlabFloats;
+    cf* slab_w = reinterpret_cast<cf*>(my_rows);
     float* __restrict__ out_clip = out + (size_t)clip * t_max * n_mels;
     double* __restrict__ st = stats + (size_t)clip * 2 * n_mels;
 
@@ -97,13 +130,22 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     // stage-2 lane roles: q = pair, k1 = row
     const int q = lane >> 4, k1 = lane & 15;
     const int partner = q * 16 + ((16 - k1) & 15);
+    // LDS float offset of this lane's A-operand row (frame ft * 16 + (lane & 15), k = lane >> 4) per frame tile
+    auto p_row = [&](int ft) {
+        const int fl = ft * 16 + (lane & 15), fw = fl / kFramesPerWave;
+        return fw * kSlabFloats + (fl - fw * kFramesPerWave) * kPStride + (lane >> 4);
+    };
+    const int prow0 = p_row(0), prow1 = p_row(1), prow2 = p_row(2), prow3 = p_row(3);
+
+    // CMVN sums of this wave's units over the run (a wave owns the same (mel tile, frame tile) units in every tile)
+    double s1[kMaxUnitsPerWave], s2[kMaxUnitsPerWave];
+#pragma unroll
+    for (int u = 0; u < kMaxUnitsPerWave; ++u) s1[u] = s2[u] = 0.0;
 
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const int t0 = tile * kTileFrames;
-        // last sample any lane of this tile may touch (frame b of the last pair, m = 17, n2 = 31)
-        const bool interior = (kHop * (t0 + kTileFrames - 1) + kFrame + 16 <= n_valid);
-        int keep = 0;
-        asm volatile("" : "+v"(keep));      // keep table loads inside the loop
+        // last sample any lane of this wave may touch (frame b of the last pair, m = 17, n2 = 31)
+        const bool interior = (kHop * (t0 + wave * kFramesPerWave + kFramesPerWave - 1) + kFrame + 16 <= n_valid);
 
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -126,6 +168,14 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
                     prv[m] = (idx - 1 < n_valid) ? x[idx > 0 ? idx - 1 : 0] : 0.0f;
                 }
             }
+            // window column and twiddles: all LDS reads are issued before the first slab write (the compiler
+            // cannot move an LDS read above an LDS write of the same array)
+            float wv[13];
+#pragma unroll
+            for (int i = 0; i < 13; ++i) wv[i] = win[32 * i + (i == 12 ? (n2 & 15) : n2)];
+            cf tw[16];
+#pragma unroll
+            for (int kk = 1; kk < 16; ++kk) tw[kk] = tw_tab[32 * kk + n2];
             // per-frame mean over n = 0..399 (n = 32 n1 + n2; n1 = 12 only for n2 < 16)
             float sa = 0.f, sb = 0.f;
 #pragma unroll
@@ -145,7 +195,6 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
             cf v[16], y[16];
 #pragma unroll
             for (int i = 0; i < 13; ++i) {
-                const float w = tab->window[32 * i + (i == 12 ? (n2 & 15) : n2) + keep];
                 // (x[n] - mu) - 0.97 (x[n-1] - mu); n == 0: 0.03 (x[0] - mu)
                 float ea = (raw[i] - 0.97f * prv[i]) - 0.03f * mu_a;
                 float eb = (raw[i + 5] - 0.97f * prv[i + 5]) - 0.03f * mu_b;
@@ -157,25 +206,26 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
                     ea = 0.f;
                     eb = 0.f;
                 }
-                v[i] = cf{ea * w, eb * w};
+                v[i] = cf{ea * wv[i], eb * wv[i]};
             }
             v[13] = v[14] = v[15] = cf{0.f, 0.f};
             dft16(v, y);
             cf* slab = slab_w + pair * kPairStride + n2;
             slab[0] = y[0];
 #pragma unroll
-            for (int kk = 1; kk < 16; ++kk) slab[kk * kRowStride] = cmul(y[kk], tw_tab[32 * kk + n2 + keep]);
+            for (int kk = 1; kk < 16; ++kk) slab[kk * kRowStride] = cmul(y[kk], tw[kk]);
         }
         wave_lds_sync2();
 
         // ---------------- stage 2: 32-point DFT over n2 ------------------------------------------
-        float pa[17], pb[17];
         {
             cf v[32], y[32];
             const cf* row = slab_w + q * kPairStride + k1 * kRowStride;
 #pragma unroll
             for (int i = 0; i < 32; ++i) v[i] = row[i];
+            wave_lds_sync2();     // this wave's panel rows (written below) alias its slab
             dft32(v, y);          // y[k2] = Z[k1 + 16 k2]
+            float* prow = my_rows + 2 * q * kPStride + k1;
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) {
                 float qr = __shfl(y[31 - k2].x, partner, 64);
@@ -186,61 +236,93 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
                 }
                 const float sr = y[k2].x + qr, dr = y[k2].x - qr;
                 const float si = y[k2].y + qi, di = y[k2].y - qi;
-                pa[k2] = sr * sr + di * di;
-                pb[k2] = si * si + dr * dr;
+                prow[16 * k2] = sr * sr + di * di;
+                prow[kPStride + 16 * k2] = si * si + dr * dr;
             }
-            pa[16] = 4.0f * y[16].x * y[16].x;     // bin 256 (k1 == 0 only)
-            pb[16] = 4.0f * y[16].y * y[16].y;
-        }
-        __syncthreads();
-        {
-            float* row = panel + (wave * kFramesPerWave + 2 * q) * kPStride + k1;
-#pragma unroll
-            for (int k2 = 0; k2 < 16; ++k2) {
-                row[16 * k2] = pa[k2];
-                row[kPStride + 16 * k2] = pb[k2];
-            }
-            if (k1 == 0) {
-                row[256] = pa[16];
-                row[kPStride + 256] = pb[16];
+            if (k1 == 0) {                         // bin 256
+                prow[256] = 4.0f * y[16].x * y[16].x;
+                prow[kPStride + 256] = 4.0f * y[16].y * y[16].y;
             }
         }
         __syncthreads();
 
         // ---------------- banded mel projection (frames x mels) + ln + CMVN statistics -----------
-        const int nu = plan.wave_nunits[wave];
-        for (int u = 0; u < nu; ++u) {
-            const int code = plan.wave_units[wave][u];
-            const int mt = code & 0xff, ft = code >> 8;
-            const int ks = plan.kstart[mt], ns = plan.nsteps[mt];
-            const float* __restrict__ w_ptr = afrag + plan.aoff[mt] + lane;
-            const float* p_ptr = panel + (ft * 16 + (lane & 15)) * kPStride + ks + (lane >> 4);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int s = 0; s < ns; ++s)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p_ptr[4 * s], w_ptr[s * 64], acc, 0, 0, 0);
-            const int mel = mt * 16 + (lane & 15);
-            const int frame0 = t0 + ft * 16 + (lane >> 4) * 4;
-            double s1 = 0.0, s2 = 0.0;     // f64 from the first add: var = E[x^2] - mean^2 cancels ~3 digits
+        int4k d = desc[0];                                          // {kstart, nsteps, aoff, mt | ft << 8}
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int frame = frame0 + r;
-                if (mel < n_mels && frame < T) {
-                    const float lg = __log2f(fmaxf(acc[r], kMelFloor)) * 0.69314718055994531f;
-                    out_clip[(size_t)frame * n_mels + mel] = lg;
-                    s1 += (double)lg;
-                    s2 += (double)lg * (double)lg;
+        for (int u = 0; u < kMaxUnitsPerWave; ++u) {
+            if (u < nu) {
+                const int ks = __builtin_amdgcn_readfirstlane(d.x);
+                const int ns = __builtin_amdgcn_readfirstlane(d.y);     // multiple of 4 (tables.cpp)
+                const int ao = __builtin_amdgcn_readfirstlane(d.z);
+                const int code = __builtin_amdgcn_readfirstlane(d.w);
+                d = desc[u + 1 < kMaxUnitsPerWave ? u + 1 : u];
+                const int mt = code & 0xff, ft = code >> 8;
+                const float* w_ptr = wfrag + ao + lane;
+                const float* p_ptr = smem + (ft == 0 ? prow0 : ft == 1 ? prow1 : ft == 2 ? prow2 : prow3) + ks;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+                float pv[4], wq[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    pv[i] = p_ptr[4 * i];
+                    wq[i] = w_ptr[i * 64];
+                }
+                for (int s = 4; s < ns; s += 4) {
+                    float pn[4], wn[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        pn[i] = p_ptr[4 * (s + i)];
+                        wn[i] = w_ptr[(s + i) * 64];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i += 2) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[i], wq[i], acc, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[i + 1], wq[i + 1], acc2, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        pv[i] = pn[i];
+                        wq[i] = wn[i];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[i], wq[i], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[i + 1], wq[i + 1], acc2, 0, 0, 0);
+                }
+                acc += acc2;
+                const int mel = mt * 16 + (lane & 15);
+                const int frame0 = t0 + ft * 16 + (lane >> 4) * 4;
+                const unsigned o0 = (unsigned)(frame0 * n_mels + mel);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (mel < n_mels && frame0 + r < T) {
+                        const float lg = __log2f(fmaxf(acc[r], kMelFloor)) * 0.69314718055994531f;
+                        out_clip[o0 + (unsigned)(r * n_mels)] = lg;
+                        s1[u] += (double)lg;         // f64 from the first add: var = E[x^2] - mean^2 cancels ~3 digits
+                        s2[u] += (double)lg * (double)lg;
+                    }
                 }
             }
-            s1 += __shfl_xor(s1, 16, 64);
-            s2 += __shfl_xor(s2, 16, 64);
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
+        }
+        __syncthreads();      // panel reads done before the next tile's slab writes
+    }
+
+    // ---------------- CMVN sums of the run: lanes l, l+16, l+32, l+48 share a mel bin ---------------
+#pragma unroll
+    for (int u = 0; u < kMaxUnitsPerWave; ++u) {
+        if (u < nu) {
+            double a = s1[u], b2 = s2[u];
+            a += __shfl_xor(a, 16, 64);
+            b2 += __shfl_xor(b2, 16, 64);
+            a += __shfl_xor(a, 32, 64);
+            b2 += __shfl_xor(b2, 32, 64);
+            const int code = reinterpret_cast<const int*>(desc)[4 * u + 3];
+            const int mel = (code & 0xff) * 16 + (lane & 15);
             if (lane < 16 && mel < n_mels) {
-                atomicAdd(&st[mel], s1);
-                atomicAdd(&st[n_mels + mel], s2);
+                atomicAdd(&st[mel], a);
+                atomicAdd(&st[n_mels + mel], b2);
             }
         }
-        __syncthreads();
     }
 }
 
@@ -263,16 +345,24 @@ __global__ __launch_bounds__(256) void kaldi_cmvn_kernel(
     }
     const int total = t_max * n_mels;
     const int stride = gridDim.x * blockDim.x;
-    const double inv_n = T > 0 ? 1.0 / (double)T : 0.0;
+    // per-bin mean and population std of the clip, once per workgroup (float64 sums -> float32, as NumPy's
+    // float32 mean / std of HF:...speech_to_text.py:150-155 up to rounding)
+    __shared__ float s_mean[128], s_std[128];
+    if ((int)threadIdx.x < n_mels) {
+        const double inv_n = T > 0 ? 1.0 / (double)T : 0.0;
+        const double mean = st[threadIdx.x] * inv_n;
+        double var = st[n_mels + threadIdx.x] * inv_n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        s_mean[threadIdx.x] = (float)mean;
+        s_std[threadIdx.x] = (float)sqrt(var);
+    }
+    __syncthreads();
+    const bool no_cmvn = flags & STTFE_KALDI_NO_CMVN;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
         const int t = e / n_mels, mel = e - t * n_mels;
         float y = 0.0f;
         if (t < T) {
-            const double mean = st[mel] * inv_n;
-            double var = st[n_mels + mel] * inv_n - mean * mean;
-            var = var > 0.0 ? var : 0.0;
-            const float meanf = (float)mean, stdf = (float)sqrt(var);
-            y = (flags & STTFE_KALDI_NO_CMVN) ? o[e] : (o[e] - meanf) / stdf;
+            y = no_cmvn ? o[e] : (o[e] - s_mean[mel]) / s_std[mel];
             for (int i = 0; i < nm; ++i) {
                 const int idx = (m_axis[i] == STTFE_AXIS_TIME) ? t : mel;
                 if (idx >= m_s[i] && idx < m_e[i]) y = 0.0f;
@@ -317,7 +407,10 @@ extern "C" int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, 
     if (hip_failed(hipMemsetAsync(stats, 0, need, stream), "hipMemsetAsync(cmvn stats)")) return STTFE_E_LAUNCH;
     const auto* tab = reinterpret_cast<const KaldiTablesHeader*>(dev_tables);
     const int n_tiles = (t_max + kaldi::kTileFrames - 1) / kaldi::kTileFrames;
-    const int tiles_per_block = 2;
+    // one workgroup per CU: runs as long as possible while the batch still gives >= 2 rounds of workgroups
+    int runs = (512 + batch - 1) / batch;
+    runs = runs < 1 ? 1 : (runs > n_tiles ? n_tiles : runs);
+    const int tiles_per_block = (n_tiles + runs - 1) / runs;
     const int bx = (n_tiles + tiles_per_block - 1) / tiles_per_block;
     {
         ScopedTiming t(kTimeKaldiFbank, stream);

@@ -16,7 +16,10 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
                 if (MODE == 0) a[i] = __builtin_fmaf(a[i], c, d);
                 else if (MODE == 1) p[i] = __builtin_elementwise_fma(p[i], c2, d2);
                 else if (MODE == 2) a[i] = a[i] + c;
-                else p[i] = p[i] + c2;
+                else if (MODE == 3) p[i] = p[i] + c2;
+                else if (MODE == 4) a[0] = __builtin_fmaf(a[0], c, d);                 // one dependent chain
+                else if (MODE == 5) a[i & 1] = __builtin_fmaf(a[i & 1], c, d);         // two chains
+                else a[i & 3] = __builtin_fmaf(a[i & 3], c, d);                        // four chains
             }
         }
     }
@@ -26,9 +29,9 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
 int main() {
     float* out; (void)hipMalloc(&out, 4096);
     const int iters = 4000;
-    const char* names[4] = {"v_fma_f32", "v_pk_fma_f32", "v_add_f32", "v_pk_add_f32"};
+    const char* names[7] = {"v_fma_f32", "v_pk_fma_f32", "v_add_f32", "v_pk_add_f32", "fma 1 chain", "fma 2 chains", "fma 4 chains"};
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int mode = 0; mode < 4; ++mode)
+    for (int mode = 4; mode < 7; ++mode)
         for (int wps = 1; wps <= 8; wps *= 2) {          // waves per SIMD: grid = 256 CUs * wps blocks of 4 waves
             dim3 grid(256 * wps), block(256);
             for (int rep = 0; rep < 2; ++rep) {
@@ -37,6 +40,9 @@ int main() {
                 if (mode == 1) hipLaunchKernelGGL(k<1>, grid, block, 0, 0, out, iters);
                 if (mode == 2) hipLaunchKernelGGL(k<2>, grid, block, 0, 0, out, iters);
                 if (mode == 3) hipLaunchKernelGGL(k<3>, grid, block, 0, 0, out, iters);
+                if (mode == 4) hipLaunchKernelGGL(k<4>, grid, block, 0, 0, out, iters);
+                if (mode == 5) hipLaunchKernelGGL(k<5>, grid, block, 0, 0, out, iters);
+                if (mode == 6) hipLaunchKernelGGL(k<6>, grid, block, 0, 0, out, iters);
                 (void)hipEventRecord(e1, 0);
                 (void)hipEventSynchronize(e1);
             }
