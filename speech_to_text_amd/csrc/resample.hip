@@ -80,11 +80,21 @@ __global__ __launch_bounds__(rs::kThreads) void decimate_peak_kernel(
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const int o0 = tile * kTile;
         __syncthreads();                                            // previous tile's row reads are done
-        // padded[ORIG * o0 + g] = x[ORIG * o0 + g - width] (zero outside the clip) -> rows[g % ORIG][g / ORIG]
-        for (int g = tid; g < ORIG * kRowLen; g += kThreads) {
+        // padded[ORIG * o0 + g] = x[ORIG * o0 + g - width] (zero outside the clip) -> rows[g % ORIG][g / ORIG].
+        // All loads of the tile are issued before the first LDS write (one HBM round trip per tile, not one
+        // per element: the compiler cannot move a load above an LDS store of the loop before it).
+        constexpr int kPerThread = (ORIG * kRowLen + kThreads - 1) / kThreads;
+        float stage[kPerThread];
+#pragma unroll
+        for (int i = 0; i < kPerThread; ++i) {
+            const int g = tid + i * kThreads;
             const int src = ORIG * o0 + g - width;
-            const float v = (src >= 0 && src < n) ? mono_at(x, n, channels, src) : 0.f;
-            rows[(g % ORIG) * kRowStride + g / ORIG] = v;
+            stage[i] = (g < ORIG * kRowLen && src >= 0 && src < n) ? mono_at(x, n, channels, src) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < kPerThread; ++i) {
+            const int g = tid + i * kThreads;
+            if (g < ORIG * kRowLen) rows[(g % ORIG) * kRowStride + g / ORIG] = stage[i];
         }
         __syncthreads();
         float acc[kOutPerThread] = {0.f, 0.f, 0.f, 0.f};
@@ -187,15 +197,36 @@ __global__ __launch_bounds__(256) void normalize_trim_kernel(
     const float top = normalize ? __fdiv_rn(peak, d) : peak;      // max|y|: division is monotonic
     const float thr = top * thr_factor;         // src/data.py:86
     int lo = 0x7fffffff, hi = -1;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float v = x[i];
-        if (normalize) {
-            v = __fdiv_rn(v, d);
-            x[i] = v;
+    // 8 elements per thread and trip: all loads are issued before the first store (in-place update: the
+    // compiler cannot hoist the next load above a store to the same array)
+    const int span = gridDim.x * blockDim.x * 8;
+    const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    for (int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8; i0 < n; i0 += span) {
+        float v[8];
+        if (vec && i0 + 8 <= n) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(x + i0), b = *reinterpret_cast<const f32x4*>(x + i0 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = (i0 + c < n) ? x[i0 + c] : 0.f;
         }
-        if (trim && fabsf(v) > thr) {
-            lo = min(lo, i);
-            hi = max(hi, i);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (normalize) v[c] = __fdiv_rn(v[c], d);
+            if (trim && i0 + c < n && fabsf(v[c]) > thr) {
+                lo = min(lo, i0 + c);
+                hi = max(hi, i0 + c);
+            }
+        }
+        if (normalize) {
+            if (vec && i0 + 8 <= n) {
+                *reinterpret_cast<f32x4*>(x + i0) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(x + i0 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (i0 + c < n) x[i0 + c] = v[c];
+            }
         }
     }
     if (trim) {
@@ -314,8 +345,8 @@ extern "C" int sttfe_normalize_trim(float* pcm, int64_t* offsets, int32_t* lengt
     }
     {
         ScopedTiming t(kTimeNormTrim, stream);
-        int bx = (int)((max_length + 256 * 8 - 1) / (256 * 8));
-        bx = bx < 1 ? 1 : (bx > 1024 ? 1024 : bx);
+        int bx = (int)((max_length + 256 * 8 - 1) / (256 * 8));      // one 8-element trip per thread
+        bx = bx < 1 ? 1 : (bx > 4096 ? 4096 : bx);
         hipLaunchKernelGGL(normalize_trim_kernel, dim3(bx, batch), dim3(256), 0, stream, pcm, offsets, lengths, keys,
                            normalize, trim, silence_threshold, first, last);
         if (trim)
