@@ -14,6 +14,8 @@ max-over-ranks time.
   s2t               configs[1]: Speech2Text fbank + CMVN, 256 ragged 2-10 s clips, dynamic padding
   resample_whisper  configs[2]: 48 kHz Common-Voice-length clips -> resample + normalise -> Whisper-80, batch 512
   whisper128_aug    configs[3]: Whisper 128-mel + SpecAugment masks, Common-Voice-length clips, batch 1024
+  corpus            configs[4]: offline precompute of a 30 000-clip (~43 h) Common-Voice-length corpus, clip i on rank
+                    i mod G, chunks of 1024 clips, Whisper-80 features (strong scaling: the corpus is fixed)
 
 roofline: dominant kernel of the workload; achieved = algorithmic bytes per launch (SURVEY.md section 8d:
 input PCM needed + output written, each once) / its average launch duration, measured with HIP events
@@ -99,7 +101,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="whisper80",
-                    choices=["whisper80", "s2t", "resample_whisper", "whisper128_aug"])
+                    choices=["whisper80", "s2t", "resample_whisper", "whisper128_aug", "corpus"])
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (0 = the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -129,9 +131,14 @@ def main():
 
     L = _lib.lib()
     wl = args.workload
-    seed = {"whisper80": 101, "s2t": 102, "resample_whisper": 103, "whisper128_aug": 104}[wl] * 1000 + rank
+    seed = {"whisper80": 101, "s2t": 102, "resample_whisper": 103, "whisper128_aug": 104, "corpus": 105}[wl] * 1000 + rank
     rng = np.random.default_rng(seed)
-    B = args.batch or {"whisper80": 1024, "s2t": 256, "resample_whisper": 512, "whisper128_aug": 1024}[wl]
+    B = args.batch or {"whisper80": 1024, "s2t": 256, "resample_whisper": 512, "whisper128_aug": 1024, "corpus": 1024}[wl]
+    if wl == "corpus":
+        from speech_to_text_amd.sharding import shard_indices
+        all_lens = common_voice_lengths(np.random.default_rng(105), 30000)          # the same corpus on every rank
+        mine = shard_indices(30000, rank, world)
+        corpus_lens = all_lens[mine]
     n_mels = 128 if wl == "whisper128_aug" else 80
     extra_kernels = []
 
@@ -145,18 +152,34 @@ def main():
     elif wl == "resample_whisper":
         lens = common_voice_lengths(rng, B) * 3                     # decoded PCM at 48 kHz
         sr = 48000
+    elif wl == "corpus":
+        lens = corpus_lens
+        sr = 16000
     else:
         lens = common_voice_lengths(rng, B)
         sr = 16000
     n_max = (int(lens.max()) + 63) // 64 * 64
-    pcm2d = synth_batch_device(seed, B, n_max, device, sample_rate=sr)
+    pcm2d = synth_batch_device(seed, len(lens), n_max, device, sample_rate=sr)
     pcm = pcm2d.reshape(-1)
-    offsets = (torch.arange(B, dtype=torch.int64) * n_max).to(device)
+    offsets = (torch.arange(len(lens), dtype=torch.int64) * n_max).to(device)
     lengths = torch.tensor(lens, dtype=torch.int32, device=device)
     host_lens = [int(v) for v in lens]
     audio_seconds = float(lens.sum()) / sr
 
-    if wl in ("whisper80", "resample_whisper", "whisper128_aug"):
+    if wl == "corpus":
+        # this rank's shard of the corpus, chunk by chunk; features of a chunk overwrite the previous chunk's
+        # (an offline precompute would hand them to the writer here)
+        fe = HipWhisperFeatureExtractor(n_mels, device=device)
+        out = torch.empty((B, n_mels, 3000), dtype=torch.float32, device=device)
+        kernel, kname = "whisper_stft_mel", "whisper_stft_mel_kernel"
+        n_local = len(lens)
+        bytes_per_launch = float(4 * np.minimum(lens, N_SAMPLES).sum() + 4 * n_mels * 3000 * n_local)   # per pass over the shard
+
+        def step():
+            for c0 in range(0, n_local, B):
+                c1 = min(c0 + B, n_local)
+                fe.extract(pcm, offsets[c0:c1], lengths[c0:c1], out=out[:c1 - c0])
+    elif wl in ("whisper80", "resample_whisper", "whisper128_aug"):
         fe = HipWhisperFeatureExtractor(n_mels, device=device)
         out = torch.empty((B, n_mels, 3000), dtype=torch.float32, device=device)
         kernel, kname = "whisper_stft_mel", "whisper_stft_mel_kernel"
@@ -221,18 +244,21 @@ def main():
     _lib.check(L.sttfe_timing_enable(0))
 
     if rank == 0:
-        clips_per_launch = B * args.steps / max(launches, 1)
+        n_clips_step = len(lens)
+        clips_per_launch = n_clips_step * args.steps / max(launches, 1)
         avg_ms = tot_ms / max(launches, 1)
-        achieved = bytes_per_launch * (clips_per_launch / B) / (avg_ms * 1e-3) / 1e9
+        achieved = bytes_per_launch * (clips_per_launch / n_clips_step) / (avg_ms * 1e-3) / 1e9
         names = {"whisper80": "log-mel audio-sec/sec (80-mel, 30 s clips)",
                  "s2t": "Speech2Text fbank+CMVN audio-sec/sec (80-mel, 2-10 s clips)",
                  "resample_whisper": "48->16 kHz resample + log-mel audio-sec/sec (80-mel, Common-Voice-length clips)",
-                 "whisper128_aug": "log-mel + SpecAugment audio-sec/sec (128-mel, Common-Voice-length clips)"}
+                 "whisper128_aug": "log-mel + SpecAugment audio-sec/sec (128-mel, Common-Voice-length clips)",
+                 "corpus": "offline log-mel precompute audio-sec/sec (80-mel, 30 000 Common-Voice-length clips)"}
         shapes = {"whisper80": f"Whisper 80-mel log-mel, {B} x 30 s clips @16 kHz per GPU (BASELINE configs[0] shape "
                                "at GPU batch; inputs resident in HBM)",
                   "s2t": f"BASELINE configs[1]: Speech2Text fbank + utterance CMVN, {B} ragged 2-10 s clips, dynamic padding",
                   "resample_whisper": f"BASELINE configs[2]: 48 kHz PCM -> resample + peak normalise -> Whisper 80-mel, {B} clips",
-                  "whisper128_aug": f"BASELINE configs[3]: Whisper 128-mel + SpecAugment masks, {B} clips"}
+                  "whisper128_aug": f"BASELINE configs[3]: Whisper 128-mel + SpecAugment masks, {B} clips",
+                  "corpus": f"BASELINE configs[4]: 30 000-clip (~43 h) corpus, clip i on rank i mod {world}, chunks of {B}"}
         result = {
             "metric": names[wl],
             "value": audio_total * args.steps / elapsed,
@@ -242,7 +268,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if wl == "corpus" else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -260,7 +286,7 @@ def main():
             n_s = 32 if wl != "s2t" else 16
             div = 3 if sr == 48000 else 1
             sample = []
-            for i in range(min(n_s, B)):
+            for i in range(min(n_s, len(lens))):
                 c = pcm2d[i, :host_lens[i]].cpu().numpy()
                 sample.append(np.ascontiguousarray(c[::div]) if div > 1 else c)     # CPU side gets 16 kHz audio
             result["cpu_baseline"] = cpu_baseline(wl, n_mels, sample)
