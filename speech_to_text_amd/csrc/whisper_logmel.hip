@@ -36,6 +36,7 @@
 
 #include "../../include/sttfe.h"
 #include "fft_core.h"
+#include "fft_pk.h"
 #include "tables.h"
 #include "timing.h"
 
@@ -51,15 +52,18 @@ constexpr int kNfft = 400;
 constexpr int kMaxSamples = 480000;           // 30 s at 16 kHz (HF:...whisper.py:91)
 constexpr int kMaxTiles = 63;                 // ceil(3000 / 48)
 constexpr int kKeysPerClip = 64;              // workspace: [0] = max key, [1 + r] = ~min key of tile run r
-constexpr int kRowStride = 21;                // float2 units, [k1][n2] rows
-constexpr int kPairStride = 420;              // float2 units per frame pair (== 4 mod 32)
-constexpr int kSlabFloats = 3 * kPairStride * 2;      // 2520 floats per wave
+constexpr int kRowStride = 22;                // complex units, [k1][n2] rows: 176 B, so a row reads as 10 x b128
+constexpr int kPairStride = 20 * kRowStride;  // complex units per frame pair (880 floats == 48 mod 64 banks)
 constexpr int kPStride = 202;                 // floats per frame row of the power panel (== 10 mod 32)
+constexpr int kSlabFloats = 2648;             // per wave: 3 pairs x 880 floats of exchange slab, aliased by 12 panel rows
+static_assert(3 * kPairStride * 2 <= kSlabFloats, "exchange slab of three frame pairs");
 static_assert(kFramesPerWave * kPStride <= kSlabFloats, "a wave's panel rows must fit inside its own slab");
 static_assert((kSlabFloats - kFramesPerWave * kPStride) % 32 == 0, "panel rows keep one bank pattern across waves");
+static_assert(kSlabFloats % 4 == 0, "16-byte aligned slabs");
 constexpr int kWinOff = kWaves * kSlabFloats;         // float offsets of the tables inside the LDS array
+constexpr int kTwStride = 44;                 // floats per lane row of the twiddle table ([j][k1] complex, padded: conflict-free b128)
 constexpr int kTwOff = kWinOff + 400;
-constexpr int kAfragOff = kTwOff + 800;               // banded mel weights in MFMA A-operand order
+constexpr int kAfragOff = kTwOff + 20 * kTwStride;               // banded mel weights in MFMA A-operand order
 constexpr int kMaxAfragFloats = 4096;                 // 53 (80 mels) / 56 (128 mels) k-steps x 64 lanes
 constexpr int kDescOff = kAfragOff + kMaxAfragFloats;     // per wave: 8 x {kstart, nsteps, aoff, mt | ft << 8}, then the unit counts
 constexpr int kLdsFloats = kDescOff + kWaves * kMaxUnitsPerWave * 4 + kWaves;   // 62032 B -> 2 workgroups per CU
@@ -145,8 +149,12 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 
     // zero the slabs once (pad cells are read by zero-weight MFMA steps and must be finite), stage tables
     for (int i = tid; i < kWinOff; i += kThreads) smem[i] = 0.f;
-    for (int i = tid; i < 400; i += kThreads) smem[kWinOff + i] = tab->window[i];
-    for (int i = tid; i < 800; i += kThreads) smem[kTwOff + i] = tab->twiddle[i];
+    // window as [j][n1] and twiddles W400^(j k1) as [j][k1]: each lane reads its 20 values as b128 words
+    for (int i = tid; i < 400; i += kThreads) smem[kWinOff + (i % 20) * 20 + i / 20] = tab->window[i];
+    for (int i = tid; i < 800; i += kThreads) {
+        const int c = i >> 1, k1 = c / 20, jj = c - 20 * k1;
+        smem[kTwOff + jj * kTwStride + 2 * k1 + (i & 1)] = tab->twiddle[i];
+    }
     {
         const float* __restrict__ afrag_g = reinterpret_cast<const float*>(tab + 1);
         const int na = min(tab->afrag_floats, kMaxAfragFloats);
@@ -171,18 +179,12 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     const int4v* desc = reinterpret_cast<const int4v*>(smem + kDescOff) + wave * kMaxUnitsPerWave;
     const int nu = __builtin_amdgcn_readfirstlane(
         reinterpret_cast<const int*>(smem + kDescOff)[4 * kWaves * kMaxUnitsPerWave + wave]);
-    const cf* tw_col = reinterpret_cast<const cf*>(smem + kTwOff) + j;
     const int partner = active ? (p * 20 + ((20 - j) % 20)) : lane;
-    cf* slab = reinterpret_cast<cf*>(smem + wave * kSlabFloats) + pa_ * kPairStride;
     float* my_rows = smem + wave * kSlabFloats;
-
-#ifdef STTFE_WIN_REGS
-    float win[20];
-#pragma unroll
-    for (int i = 0; i < 20; ++i) win[i] = smem[kWinOff + 20 * i + j];
-#else
-    const float* win = smem + kWinOff + j;
-#endif
+    f2* slab_w = reinterpret_cast<f2*>(my_rows) + pa_ * kPairStride + j;                        // stage-1 writes: [k1][n2 = j]
+    const f32x4* slab_r = reinterpret_cast<const f32x4*>(my_rows + 2 * (pa_ * kPairStride + j * kRowStride));   // row k1 = j
+    const f32x4* win4 = reinterpret_cast<const f32x4*>(smem + kWinOff + 20 * j);
+    const f32x4* tw4 = reinterpret_cast<const f32x4*>(smem + kTwOff + kTwStride * j);
 
     // SpecAugment: mel-axis masks as two 64-bit words for the clip; time-axis masks per tile
     const int32_t* __restrict__ clip_masks = mask_tbl ? mask_tbl + (size_t)clip * n_masks * 3 : nullptr;
@@ -214,69 +216,69 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         }
     };
 
-    // one pass: window, 20 x 20 DFT through the slab, spectra separation -> 4 |A|^2, 4 |B|^2 (bins j + 20 k2)
+    // one pass: window, 20 x 20 DFT through the slab, spectra separation -> 4 |A|^2, 4 |B|^2 (bins j + 20 k2).
+    // Complex values live in even-aligned register pairs and go through the packed-f32 forms of fft_pk.h.
     auto fft_stage1 = [&](const float (&raw)[28]) {
-        cf v[20], y[20];
+        f2 v[20], y[20];
+        // all table reads are issued before the first slab write: the compiler cannot move an LDS read
+        // above an LDS write of the same array, and one read-wait-write round trip per row costs ~1k cycles
+        f32x4 w4[5], t4[10];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) w4[q] = win4[q];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) t4[q] = tw4[q];
 #pragma unroll
         for (int i = 0; i < 20; ++i) {
-#ifdef STTFE_WIN_REGS
-            const float w = win[i];
-#else
-#ifdef ABL_NOWIN
-            const float w = 0.5f + i;
-#else
-            const float w = win[20 * i];
-#endif
-#endif
-            v[i] = cf{raw[i] * w, raw[i + 8] * w};
+            const float w = w4[i >> 2][i & 3];
+            v[i] = f2{raw[i] * w, raw[i + 8] * w};
         }
-        // all twiddle reads are issued before the first slab write: the compiler cannot move an LDS read
-        // above an LDS write of the same array, and one read-wait-write round trip per row costs ~1k cycles
-        cf tw[20];
-#pragma unroll
-        for (int k1 = 1; k1 < 20; ++k1) tw[k1] = tw_col[20 * k1];
-        dft20(v, y);
+        dft20_pk(v, y);
         if (active) {
-            slab[j] = y[0];
+            slab_w[0] = y[0];
 #pragma unroll
-            for (int k1 = 1; k1 < 20; ++k1) slab[k1 * kRowStride + j] = cmul(y[k1], tw[k1]);
+            for (int k1 = 1; k1 < 20; ++k1) {
+                const f2 tw = {t4[k1 >> 1][2 * (k1 & 1)], t4[k1 >> 1][2 * (k1 & 1) + 1]};
+                slab_w[k1 * kRowStride] = cmul_pk(y[k1], tw);
+            }
         }
         wave_lds_sync();
     };
-    auto fft_stage2 = [&](float (&pa)[11], float (&pb)[11]) {
-        cf v[20], y[20];
+    auto fft_stage2 = [&](f2 (&pw)[11]) {
+        f2 v[20], y[20];
+        f32x4 r4[10];
 #pragma unroll
-        for (int n2 = 0; n2 < 20; ++n2) v[n2] = slab[j * kRowStride + n2];
+        for (int q = 0; q < 10; ++q) r4[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (active) {
+#pragma unroll
+            for (int q = 0; q < 10; ++q) r4[q] = slab_r[q];
+        }
         wave_lds_sync();      // the next writes to the slab (next pass / panel rows) come after these reads
-        dft20(v, y);          // y[k2] = Z[j + 20 k2]
+#pragma unroll
+        for (int q = 0; q < 10; ++q) {
+            v[2 * q] = f2{r4[q][0], r4[q][1]};
+            v[2 * q + 1] = f2{r4[q][2], r4[q][3]};
+        }
+        dft20_pk(v, y);       // y[k2] = Z[j + 20 k2]
 #pragma unroll
         for (int k2 = 0; k2 < 10; ++k2) {
-            float qr = __shfl(y[19 - k2].x, partner, 64);
-            float qi = __shfl(y[19 - k2].y, partner, 64);
-            if (j == 0) {                                         // own Z[400 - 20 k2]
-                qr = (k2 == 0) ? y[0].x : y[20 - k2].x;
-                qi = (k2 == 0) ? y[0].y : y[20 - k2].y;
-            }
-            const float sr = y[k2].x + qr, dr = y[k2].x - qr;
-            const float si = y[k2].y + qi, di = y[k2].y - qi;
-            pa[k2] = sr * sr + di * di;                           // 4 |A[k]|^2
-            pb[k2] = si * si + dr * dr;                           // 4 |B[k]|^2
+            f2 q = {__shfl(y[19 - k2].x, partner, 64), __shfl(y[19 - k2].y, partner, 64)};
+            if (j == 0) q = (k2 == 0) ? y[0] : y[20 - k2];        // own Z[400 - 20 k2]
+            pw[k2] = power_pair(y[k2] + q, y[k2] - q);            // (4 |A[k]|^2, 4 |B[k]|^2)
         }
-        pa[10] = 4.0f * y[10].x * y[10].x;                        // bin 200 (lane j == 0 only)
-        pb[10] = 4.0f * y[10].y * y[10].y;
+        pw[10] = y[10] * y[10] * 4.0f;                            // bin 200 (lane j == 0 only)
     };
 
-    auto store_rows = [&](int pass, const float (&pa)[11], const float (&pb)[11]) {
+    auto store_rows = [&](int pass, const f2 (&pw)[11]) {
         if (!active) return;
         float* row = my_rows + (6 * pass + 2 * p) * kPStride + j;
 #pragma unroll
         for (int k2 = 0; k2 < 10; ++k2) {
-            row[20 * k2] = pa[k2];
-            row[kPStride + 20 * k2] = pb[k2];
+            row[20 * k2] = pw[k2].x;
+            row[kPStride + 20 * k2] = pw[k2].y;
         }
         if (j == 0) {
-            row[200] = pa[10];
-            row[kPStride + 200] = pb[10];
+            row[200] = pw[10].x;
+            row[kPStride + 200] = pw[10].y;
         }
     };
 
@@ -302,22 +304,22 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const int t0 = tile * kTileFrames;
-        float pa0[11], pb0[11], pa1[11], pb1[11];
+        f2 pw0[11], pw1[11];
         const bool more = tile + 1 < tile_end;
 
         fft_stage1(raw0);
         STAMP(0);
         if (more) load_pass(t0 + kTileFrames, 0, raw0);
-        fft_stage2(pa0, pb0);
+        fft_stage2(pw0);
         STAMP(2);
         fft_stage1(raw1);
         STAMP(3);
         if (more) load_pass(t0 + kTileFrames, 1, raw1);
-        fft_stage2(pa1, pb1);
+        fft_stage2(pw1);
         STAMP(4);
 
-        store_rows(0, pa0, pb0);
-        store_rows(1, pa1, pb1);
+        store_rows(0, pw0);
+        store_rows(1, pw1);
         STAMP(5);
         __syncthreads();                                           // panel complete
         STAMP(6);

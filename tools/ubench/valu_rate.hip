@@ -31,7 +31,7 @@ int main() {
     const int iters = 4000;
     const char* names[7] = {"v_fma_f32", "v_pk_fma_f32", "v_add_f32", "v_pk_add_f32", "fma 1 chain", "fma 2 chains", "fma 4 chains"};
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int mode = 4; mode < 7; ++mode)
+    for (int mode = 0; mode < 7; ++mode)
         for (int wps = 1; wps <= 8; wps *= 2) {          // waves per SIMD: grid = 256 CUs * wps blocks of 4 waves
             dim3 grid(256 * wps), block(256);
             for (int rep = 0; rep < 2; ++rep) {
