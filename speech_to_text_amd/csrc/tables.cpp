@@ -68,7 +68,8 @@ void kaldi_mel_bank(int n_mels, std::vector<float>& dense) {
 
 // Build the banded MFMA plan + A fragments from a dense (n_mels x n_bins) bank times `scale`.
 void build_mel_plan(const std::vector<float>& dense, int n_mels, int n_bins, float scale,
-                    int n_waves, int n_ftiles, int step_multiple, MelPlan& plan, std::vector<float>& afrag) {
+                    int n_waves, int n_ftiles, int step_multiple, int row_floats, MelPlan& plan,
+                    std::vector<float>& afrag) {
     std::memset(&plan, 0, sizeof(plan));
     plan.n_mels = n_mels;
     plan.n_bins = n_bins;
@@ -87,15 +88,31 @@ void build_mel_plan(const std::vector<float>& dense, int n_mels, int n_bins, flo
         }
         int nsteps = 0, kstart = 0;
         if (hi >= lo) {
+            if (row_floats > 0) lo &= ~3;             // grouped layout: 16-byte aligned operand reads
             nsteps = (hi - lo + 1 + 3) / 4;
             // zero-weight steps pad the band to a multiple of step_multiple (the kernel batches its loads)
             nsteps = (nsteps + step_multiple - 1) / step_multiple * step_multiple;
-            // never read past the row: the panel row holds n_bins values + 1 finite pad cell
-            kstart = std::max(0, std::min(lo, n_bins + 1 - 4 * nsteps));
+            // never read past the row: the panel row holds n_bins values + finite pad cells
+            const int row_len = row_floats > 0 ? row_floats : n_bins + 1;
+            kstart = std::max(0, std::min(lo, row_len - 4 * nsteps));
         }
         plan.kstart[mt] = kstart;
         plan.nsteps[mt] = nsteps;
         plan.aoff[mt] = (int32_t)afrag.size();
+        if (row_floats > 0) {
+            // grouped: [group of 4 steps][lane][step in group]; step i of group g covers bins
+            // kstart + 16 g + 4 (lane >> 4) + i, so a lane's four A values and four B values are one b128 each
+            for (int g = 0; g < nsteps / 4; ++g)
+                for (int l = 0; l < 64; ++l)
+                    for (int i = 0; i < 4; ++i) {
+                        const int m = mt * 16 + (l & 15);
+                        const int k = kstart + 16 * g + 4 * (l >> 4) + i;
+                        float v = 0.0f;
+                        if (m < n_mels && k < n_bins) v = dense[(size_t)m * n_bins + k] * scale;
+                        afrag.push_back(v);
+                    }
+            continue;
+        }
         for (int s = 0; s < nsteps; ++s)
             for (int l = 0; l < 64; ++l) {
                 const int m = mt * 16 + (l & 15);
@@ -142,7 +159,7 @@ static int whisper_tables(int n_mels, std::vector<unsigned char>& blob) {
     std::memset(&h, 0, sizeof(h));
     // 0.25 = the 1/4 of the two-real-frames-in-one-complex-FFT separation, folded into the bank
     // (a power of two: bit-identical to scaling the power spectrum itself).
-    build_mel_plan(dense, n_mels, 201, 0.25f, 4, kFrameTiles, 4, h.plan, afrag);   // 4 waves x 3 frame tiles
+    build_mel_plan(dense, n_mels, 201, 0.25f, 4, kFrameTiles, 4, 204, h.plan, afrag);   // 4 waves x 3 frame tiles, grouped b128 layout, 204-float panel rows
     h.magic = kWhisperMagic;
     h.n_mels = n_mels;
     h.afrag_floats = (int32_t)afrag.size();
@@ -195,7 +212,7 @@ static int kaldi_tables(int n_mels, std::vector<unsigned char>& blob) {
     std::memset(&h, 0, sizeof(h));
     // 2^28 = (2^15)^2 [the x * 2**15 of HF speech_to_text.py:112 applied to the power spectrum] * 1/4
     // [two-real-frames separation]; a power of two, so folding it into the bank is exact.
-    build_mel_plan(dense, n_mels, 257, 268435456.0f, 8, 4, 4, h.plan, afrag);   // 8 waves x 4 frame tiles, bands padded to 4 steps
+    build_mel_plan(dense, n_mels, 257, 268435456.0f, 8, 4, 4, 0, h.plan, afrag);   // 8 waves x 4 frame tiles, bands padded to 4 steps
     h.magic = kKaldiMagic;
     h.n_mels = n_mels;
     h.afrag_floats = (int32_t)afrag.size();

@@ -54,17 +54,17 @@ constexpr int kMaxTiles = 63;                 // ceil(3000 / 48)
 constexpr int kKeysPerClip = 64;              // workspace: [0] = max key, [1 + r] = ~min key of tile run r
 constexpr int kRowStride = 22;                // complex units, [k1][n2] rows: 176 B, so a row reads as 10 x b128
 constexpr int kPairStride = 20 * kRowStride;  // complex units per frame pair (880 floats == 48 mod 64 banks)
-constexpr int kPStride = 202;                 // floats per frame row of the power panel (== 10 mod 32)
-constexpr int kSlabFloats = 2648;             // per wave: 3 pairs x 880 floats of exchange slab, aliased by 12 panel rows
+constexpr int kPStride = 204;                 // floats per frame row of the power panel: 16-byte rows, 12 n mod 64 banks -> conflict-free b128 operand reads
+constexpr int kSlabFloats = 2640;             // per wave: 3 pairs x 880 floats of exchange slab, aliased by 12 panel rows
 static_assert(3 * kPairStride * 2 <= kSlabFloats, "exchange slab of three frame pairs");
 static_assert(kFramesPerWave * kPStride <= kSlabFloats, "a wave's panel rows must fit inside its own slab");
-static_assert((kSlabFloats - kFramesPerWave * kPStride) % 32 == 0, "panel rows keep one bank pattern across waves");
+static_assert((kSlabFloats - kFramesPerWave * kPStride) % 64 == 0, "panel rows keep one bank pattern across waves");
 static_assert(kSlabFloats % 4 == 0, "16-byte aligned slabs");
 constexpr int kWinOff = kWaves * kSlabFloats;         // float offsets of the tables inside the LDS array
 constexpr int kTwStride = 44;                 // floats per lane row of the twiddle table ([j][k1] complex, padded: conflict-free b128)
 constexpr int kTwOff = kWinOff + 400;
 constexpr int kAfragOff = kTwOff + 20 * kTwStride;               // banded mel weights in MFMA A-operand order
-constexpr int kMaxAfragFloats = 4096;                 // 53 (80 mels) / 56 (128 mels) k-steps x 64 lanes
+constexpr int kMaxAfragFloats = 4608;                 // 53 (80 mels) / 56 (128 mels) k-steps x 64 lanes
 constexpr int kDescOff = kAfragOff + kMaxAfragFloats;     // per wave: 8 x {kstart, nsteps, aoff, mt | ft << 8}, then the unit counts
 constexpr int kLdsFloats = kDescOff + kWaves * kMaxUnitsPerWave * 4 + kWaves;   // 62032 B -> 2 workgroups per CU
 }  // namespace wh
@@ -287,11 +287,11 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         for (int i = 0; i < EXP_DEPHASE; ++i) __builtin_amdgcn_s_sleep(127);     // ~127 * 64 cycles each
     }
 #endif
-    float run_max = -3.0e38f, run_min = 3.0e38f;
+    float run_max = 0.0f, run_min = 3.0e38f;        // mel energies (>= 1e-10 once any cell was produced)
     // LDS float offset of this lane's B-operand row (frame ft * 16 + (lane & 15), k = lane >> 4) per frame tile
     auto b_row = [&](int ft) {
         const int fl = ft * 16 + (lane & 15), fw = fl / kFramesPerWave;
-        return fw * kSlabFloats + (fl - fw * kFramesPerWave) * kPStride + (lane >> 4);
+        return fw * kSlabFloats + (fl - fw * kFramesPerWave) * kPStride + 4 * (lane >> 4);
     };
     const int brow0 = b_row(0), brow1 = b_row(1), brow2 = b_row(2);
     float raw0[28], raw1[28];                      // the two passes of the NEXT tile, loaded a whole tile ahead
@@ -326,66 +326,67 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 
         // ---------------- banded mel projection on the matrix cores + log epilogue --------------
         const uint64_t tmask = mask_bits(clip_masks, nm, STTFE_AXIS_TIME, t0, kTileFrames);
+        // Operands come as one b128 per lane and group of four k-steps: step i of group g multiplies bins
+        // kstart + 16 g + 4 (lane >> 4) + i (tables.cpp lays the mel weights out to match).  Two interleaved
+        // accumulation chains hide the 40-cycle dependent latency of the 16x16x4 MFMA; the next group's
+        // operands -- across unit boundaries too -- are read while the current four steps multiply.
+        // (Running a unit's epilogue under the first MFMAs of the next unit was measured slower: 1.15 vs 1.08 ms.)
         int4v d = desc[0];                                          // {kstart, nsteps, aoff, mt | ft << 8}
+        int ks = __builtin_amdgcn_readfirstlane(d.x), ns = __builtin_amdgcn_readfirstlane(d.y);
+        int ao = __builtin_amdgcn_readfirstlane(d.z), code = __builtin_amdgcn_readfirstlane(d.w);
+        d = desc[1];
+        const f32x4* a_ptr = reinterpret_cast<const f32x4*>(afrag + ao) + lane;
+        const f32x4* b_ptr = reinterpret_cast<const f32x4*>(smem + ((code >> 8) == 0 ? brow0 : ((code >> 8) == 1 ? brow1 : brow2)) + ks);
+        f32x4 av = a_ptr[0], bv = b_ptr[0];
         for (int u = 0; u < nu; ++u) {
-            const int ks = __builtin_amdgcn_readfirstlane(d.x);
-            const int ns = __builtin_amdgcn_readfirstlane(d.y);     // multiple of 4 (tables.cpp)
-            const int ao = __builtin_amdgcn_readfirstlane(d.z);
-            const int code = __builtin_amdgcn_readfirstlane(d.w);
-            d = desc[min(u + 1, kMaxUnitsPerWave - 1)];             // next unit's descriptor lands during this one
-            const int mt = code & 0xff, ft = code >> 8;
-            const float* a_ptr = afrag + ao + lane;
-            const float* b_ptr = smem + (ft == 0 ? brow0 : (ft == 1 ? brow1 : brow2)) + ks;
-            // two interleaved accumulation chains hide the 40-cycle dependent latency of the 16x16x4 MFMA;
-            // the operands of the next four steps are read while the current four multiply
+            const int mt = code & 0xff, ft = code >> 8, ng = ns >> 2;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-            float av[4], bv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                av[i] = a_ptr[i * 64];
-                bv[i] = b_ptr[4 * i];
+            for (int g = 1; g < ng; ++g) {
+                const f32x4 an = a_ptr[g * 64], bn = b_ptr[4 * g];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc2, 0, 0, 0);
+                av = an;
+                bv = bn;
             }
-            for (int s = 4; s < ns; s += 4) {
-                float an[4], bn[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    an[i] = a_ptr[(s + i) * 64];
-                    bn[i] = b_ptr[4 * (s + i)];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; i += 2) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i + 1], bv[i + 1], acc2, 0, 0, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    av[i] = an[i];
-                    bv[i] = bn[i];
-                }
+            f32x4 an = av, bn = bv;
+            if (u + 1 < nu) {                                       // first group of the next unit
+                ks = __builtin_amdgcn_readfirstlane(d.x);
+                ns = __builtin_amdgcn_readfirstlane(d.y);
+                ao = __builtin_amdgcn_readfirstlane(d.z);
+                code = __builtin_amdgcn_readfirstlane(d.w);
+                d = desc[min(u + 2, kMaxUnitsPerWave - 1)];
+                a_ptr = reinterpret_cast<const f32x4*>(afrag + ao) + lane;
+                b_ptr = reinterpret_cast<const f32x4*>(smem + ((code >> 8) == 0 ? brow0 : ((code >> 8) == 1 ? brow1 : brow2)) + ks);
+                an = a_ptr[0];
+                bn = b_ptr[0];
             }
-#pragma unroll
-            for (int i = 0; i < 4; i += 2) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i + 1], bv[i + 1], acc2, 0, 0, 0);
-            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc2, 0, 0, 0);
+            av = an;
+            bv = bn;
             acc += acc2;
             STAMP(9);
             const int fl = ft * 16 + (lane & 15);                  // frame within the tile
             const int mel0 = mt * 16 + (lane >> 4) * 4;
             const unsigned o0 = (unsigned)(mel0 * n_frames + t0 + fl);
-            float yv[4];
+            // max / min are tracked on the mel energies themselves (log is monotonic); y = (log10(m) + 4) / 4
+            float mv[4], yv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float lg = __log2f(fmaxf(acc[r], 1e-10f)) * 0.30102999566398120f;
-                yv[r] = lg;
+                mv[r] = fmaxf(acc[r], 1e-10f);
+                yv[r] = fmaf(__log2f(mv[r]), 0.25f * 0.30102999566398120f, 1.0f);
             }
             const bool whole = (mt * 16 + 16 <= n_mels) && (t0 + ft * 16 + 16 <= n_frames);    // wave-uniform
             if (whole && nm == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    run_max = fmaxf(run_max, yv[r]);
-                    run_min = fminf(run_min, yv[r]);
-                    out_clip[o0 + (unsigned)(r * n_frames)] = (yv[r] + 4.0f) * 0.25f;
+                    run_max = fmaxf(run_max, mv[r]);
+                    run_min = fminf(run_min, mv[r]);
+                    out_clip[o0 + (unsigned)(r * n_frames)] = yv[r];
                 }
             } else {
                 const bool tmasked = (tmask >> fl) & 1ull;
@@ -393,10 +394,9 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (mel0 + r < n_mels && t0 + fl < n_frames) {
-                        run_max = fmaxf(run_max, yv[r]);
-                        run_min = fminf(run_min, yv[r]);
-                        out_clip[o0 + (unsigned)(r * n_frames)] =
-                            (tmasked || ((mbits >> r) & 1u)) ? 0.0f : (yv[r] + 4.0f) * 0.25f;
+                        run_max = fmaxf(run_max, mv[r]);
+                        run_min = fminf(run_min, mv[r]);
+                        out_clip[o0 + (unsigned)(r * n_frames)] = (tmasked || ((mbits >> r) & 1u)) ? 0.0f : yv[r];
                     }
                 }
             }
@@ -418,9 +418,9 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         run_max = fmaxf(run_max, __shfl_xor(run_max, off, 64));
         run_min = fminf(run_min, __shfl_xor(run_min, off, 64));
     }
-    if (lane == 0) {
-        atomicMax(&keys[(size_t)clip * kKeysPerClip], float_to_key(run_max));
-        atomicMax(&keys[(size_t)clip * kKeysPerClip + 1 + blockIdx.x], ~float_to_key(run_min));
+    if (lane == 0 && run_max > 0.0f) {
+        atomicMax(&keys[(size_t)clip * kKeysPerClip], float_to_key(__log2f(run_max) * 0.30102999566398120f));
+        atomicMax(&keys[(size_t)clip * kKeysPerClip + 1 + blockIdx.x], ~float_to_key(__log2f(run_min) * 0.30102999566398120f));
     }
 }
 
@@ -583,7 +583,13 @@ extern "C" int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, co
     const auto* tab = reinterpret_cast<const WhisperTablesHeader*>(dev_tables);
     {
         ScopedTiming t(kTimeWhisperStftMel, stream);
-        hipLaunchKernelGGL(whisper_stft_mel_kernel, dim3(blocks_x, batch), dim3(wh::kThreads), 0, stream,
+#ifdef STTFE_STAMPS
+        // diagnostic build: extra dynamic LDS forces one workgroup per CU (phase times without a co-resident workgroup)
+        static const int dyn_lds = getenv("STTFE_WH_DYN_LDS") ? atoi(getenv("STTFE_WH_DYN_LDS")) : 0;
+#else
+        const int dyn_lds = 0;
+#endif
+        hipLaunchKernelGGL(whisper_stft_mel_kernel, dim3(blocks_x, batch), dim3(wh::kThreads), dyn_lds, stream,
                            pcm, offsets, lengths, n_mels, n_frames, tab, out, keys, mask_tbl, n_masks, tiles_per_block);
     }
     {
