@@ -17,7 +17,7 @@
 //     The PCM of the NEXT pass is loaded into registers at the start of each pass, so a full pass of
 //     arithmetic hides the HBM latency; the window column lives in registers.
 //   * |A|^2, |B|^2 of both passes stay in registers until the wave's last slab read, then go to the
-//     wave's own 12 rows of the [frame][bin] power panel (row stride 202 floats), which aliases the
+//     wave's own 12 rows of the [frame][bin] power panel (row stride 204 floats), which aliases the
 //     wave's own slab: no workgroup barrier between FFT and panel.
 //   * barrier; banded mel projection on the matrix cores: exact-f32 v_mfma_f32_16x16x4_f32 tiles
 //     (16 mel rows x 16 frames) over only the bins each 16-row band of the triangular bank touches
@@ -27,12 +27,14 @@
 //     applied from per-tile / per-clip bit masks; per-clip max and per-tile min of log10 go to the
 //     workspace with one atomic per wave.
 //   Tiles that lie entirely in the 30 s zero padding are left to kernel 2 (they are constant).
-// Kernel 2 (clamp_fill): one small workgroup per (clip, tile).  Padding tiles are filled with the final
-//   constant (write only); a computed tile is re-read and clamped to (max - 8 + 4) / 4 only when its
-//   recorded minimum is below max - 8 (otherwise it is already final and the workgroup exits).
+// Kernel 2 (clamp_fill): 8 workgroups per clip, each owning every 8th mel row.  The zero-padding region is filled
+//   with the final constant (write only); of the computed tiles only those whose recorded minimum is below
+//   max - 8 are re-read and clamped to (max - 8 + 4) / 4 (everything else is already final).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "../../include/sttfe.h"
 #include "fft_core.h"
@@ -51,7 +53,7 @@ constexpr int kHop = 160;
 constexpr int kNfft = 400;
 constexpr int kMaxSamples = 480000;           // 30 s at 16 kHz (HF:...whisper.py:91)
 constexpr int kMaxTiles = 63;                 // ceil(3000 / 48)
-constexpr int kKeysPerClip = 64;              // workspace: [0] = max key, [1 + r] = ~min key of tile run r
+constexpr int kKeysPerClip = 64;              // workspace: [0] = max key, [1 + t] = ~min key of tile t
 constexpr int kRowStride = 22;                // complex units, [k1][n2] rows: 176 B, so a row reads as 10 x b128
 constexpr int kPairStride = 20 * kRowStride;  // complex units per frame pair (880 floats == 48 mod 64 banks)
 constexpr int kPStride = 204;                 // floats per frame row of the power panel: 16-byte rows, 12 n mod 64 banks -> conflict-free b128 operand reads
@@ -86,6 +88,24 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Wave-wide minimum without the LDS pipe: DPP swizzles inside each row of 16 lanes (quad swaps, half-row and row
+// mirrors), then the four row results through scalar registers.  (Six dependent ds_bpermute steps cost ~700 cycles.)
+__device__ __forceinline__ float wave_min(float v) {
+    auto step = [](float x, auto ctrl) {
+        const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false);
+        return fminf(x, __int_as_float(y));
+    };
+    v = step(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+    v = step(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+    v = step(v, std::integral_constant<int, 0x141>{});     // row_half_mirror
+    v = step(v, std::integral_constant<int, 0x140>{});     // row_mirror
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fminf(fminf(a, b), fminf(c, d));
 }
 
 // Bits [0, width) of the result mark the indices base + i covered by a mask of the given axis.
@@ -216,54 +236,70 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         }
     };
 
-    // one pass: window, 20 x 20 DFT through the slab, spectra separation -> 4 |A|^2, 4 |B|^2 (bins j + 20 k2).
-    // Complex values live in even-aligned register pairs and go through the packed-f32 forms of fft_pk.h.
-    auto fft_stage1 = [&](const float (&raw)[28]) {
-        f2 v[20], y[20];
-        // all table reads are issued before the first slab write: the compiler cannot move an LDS read
-        // above an LDS write of the same array, and one read-wait-write round trip per row costs ~1k cycles
-        f32x4 w4[5], t4[10];
+    // Window and twiddles of this lane stay in registers for the whole tile run (60 VGPRs).
+    f32x4 w4[5], t4[10];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) w4[q] = win4[q];
+    for (int q = 0; q < 5; ++q) w4[q] = win4[q];
 #pragma unroll
-        for (int q = 0; q < 10; ++q) t4[q] = tw4[q];
+    for (int q = 0; q < 10; ++q) t4[q] = tw4[q];
+
+    // The FFT of one pass (3 frame pairs) in four pieces, so that the tile loop can interleave the two passes and
+    // put arithmetic of one pass under the LDS latencies of the other.  Complex values live in even-aligned
+    // register pairs and go through the packed-f32 forms of fft_pk.h.
+    //   s1_math  : window, 20-point DFTs over n1, twiddles
+    //   s1_write : [k1][n2] rows into the wave's exchange slab
+    //   s2_read  : row k1 = j back as 10 x b128 (issued early, consumed after other work)
+    //   s2_math  : 20-point DFTs over n2: y[k2] = Z[j + 20 k2]
+    //   sep_*    : partner lane's Z[400 - k] by ds_bpermute, then 4 |A|^2, 4 |B|^2 for bins j + 20 k2
+    auto s1_math = [&](const float (&raw)[28], f2 (&y)[20]) {
+        f2 v[20];
 #pragma unroll
         for (int i = 0; i < 20; ++i) {
             const float w = w4[i >> 2][i & 3];
             v[i] = f2{raw[i] * w, raw[i + 8] * w};
         }
         dft20_pk(v, y);
-        if (active) {
-            slab_w[0] = y[0];
 #pragma unroll
-            for (int k1 = 1; k1 < 20; ++k1) {
-                const f2 tw = {t4[k1 >> 1][2 * (k1 & 1)], t4[k1 >> 1][2 * (k1 & 1) + 1]};
-                slab_w[k1 * kRowStride] = cmul_pk(y[k1], tw);
-            }
+        for (int k1 = 1; k1 < 20; ++k1) {
+            const f2 tw = {t4[k1 >> 1][2 * (k1 & 1)], t4[k1 >> 1][2 * (k1 & 1) + 1]};
+            y[k1] = cmul_pk(y[k1], tw);
+        }
+    };
+    auto s1_write = [&](const f2 (&y)[20]) {
+        wave_lds_sync();      // after every earlier read of the slab / panel rows by this wave
+        if (active) {
+#pragma unroll
+            for (int k1 = 0; k1 < 20; ++k1) slab_w[k1 * kRowStride] = y[k1];
         }
         wave_lds_sync();
     };
-    auto fft_stage2 = [&](f2 (&pw)[11]) {
-        f2 v[20], y[20];
-        f32x4 r4[10];
+    auto s2_read = [&](f32x4 (&r4)[10]) {
 #pragma unroll
         for (int q = 0; q < 10; ++q) r4[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (active) {
 #pragma unroll
             for (int q = 0; q < 10; ++q) r4[q] = slab_r[q];
         }
-        wave_lds_sync();      // the next writes to the slab (next pass / panel rows) come after these reads
+    };
+    auto s2_math = [&](const f32x4 (&r4)[10], f2 (&y)[20]) {
+        f2 v[20];
 #pragma unroll
         for (int q = 0; q < 10; ++q) {
             v[2 * q] = f2{r4[q][0], r4[q][1]};
             v[2 * q + 1] = f2{r4[q][2], r4[q][3]};
         }
-        dft20_pk(v, y);       // y[k2] = Z[j + 20 k2]
+        dft20_pk(v, y);
+    };
+    auto sep_fetch = [&](const f2 (&y)[20], f2 (&q)[10]) {
+#pragma unroll
+        for (int k2 = 0; k2 < 10; ++k2)
+            q[k2] = f2{__shfl(y[19 - k2].x, partner, 64), __shfl(y[19 - k2].y, partner, 64)};
+    };
+    auto sep_math = [&](const f2 (&y)[20], const f2 (&q)[10], f2 (&pw)[11]) {
 #pragma unroll
         for (int k2 = 0; k2 < 10; ++k2) {
-            f2 q = {__shfl(y[19 - k2].x, partner, 64), __shfl(y[19 - k2].y, partner, 64)};
-            if (j == 0) q = (k2 == 0) ? y[0] : y[20 - k2];        // own Z[400 - 20 k2]
-            pw[k2] = power_pair(y[k2] + q, y[k2] - q);            // (4 |A[k]|^2, 4 |B[k]|^2)
+            const f2 qq = (j == 0) ? ((k2 == 0) ? y[0] : y[20 - k2]) : q[k2];      // lane 0: own Z[400 - 20 k2]
+            pw[k2] = power_pair(y[k2] + qq, y[k2] - qq);          // (4 |A[k]|^2, 4 |B[k]|^2)
         }
         pw[10] = y[10] * y[10] * 4.0f;                            // bin 200 (lane j == 0 only)
     };
@@ -287,7 +323,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         for (int i = 0; i < EXP_DEPHASE; ++i) __builtin_amdgcn_s_sleep(127);     // ~127 * 64 cycles each
     }
 #endif
-    float run_max = 0.0f, run_min = 3.0e38f;        // mel energies (>= 1e-10 once any cell was produced)
+    float run_max = 0.0f;                           // mel energies (>= 1e-10 once any cell was produced)
     // LDS float offset of this lane's B-operand row (frame ft * 16 + (lane & 15), k = lane >> 4) per frame tile
     auto b_row = [&](int ft) {
         const int fl = ft * 16 + (lane & 15), fw = fl / kFramesPerWave;
@@ -304,22 +340,34 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const int t0 = tile * kTileFrames;
-        f2 pw0[11], pw1[11];
-        const bool more = tile + 1 < tile_end;
-
-        fft_stage1(raw0);
-        STAMP(0);
-        if (more) load_pass(t0 + kTileFrames, 0, raw0);
-        fft_stage2(pw0);
-        STAMP(2);
-        fft_stage1(raw1);
-        STAMP(3);
-        if (more) load_pass(t0 + kTileFrames, 1, raw1);
-        fft_stage2(pw1);
-        STAMP(4);
-
-        store_rows(0, pw0);
-        store_rows(1, pw1);
+        {
+            f2 ya[20], yb[20], pw0[11], pw1[11], q0[10], q1[10];
+            f32x4 ra[10], rb[10];
+            s1_math(raw0, ya);
+            s1_write(ya);
+            s2_read(ra);                       // pass 0 rows in flight ...
+            s1_math(raw1, yb);                 // ... under the first-stage arithmetic of pass 1
+            STAMP(0);
+            s1_write(yb);                      // LDS runs a wave's operations in order: after the reads above
+            s2_read(rb);
+            s2_math(ra, ya);                   // under the pass-1 reads
+            sep_fetch(ya, q0);
+            STAMP(2);
+            s2_math(rb, yb);                   // under the pass-0 partner exchange
+            sep_fetch(yb, q1);
+            sep_math(ya, q0, pw0);
+            STAMP(3);
+            sep_math(yb, q1, pw1);
+            wave_lds_sync();                   // panel rows alias the slab: after its last read
+            STAMP(4);
+            store_rows(0, pw0);
+            store_rows(1, pw1);
+        }
+        // next tile's PCM: issued now (few live registers from here on), lands during the mel projection
+        if (tile + 1 < tile_end) {
+            load_pass(t0 + kTileFrames, 0, raw0);
+            load_pass(t0 + kTileFrames, 1, raw1);
+        }
         STAMP(5);
         __syncthreads();                                           // panel complete
         STAMP(6);
@@ -331,6 +379,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         // accumulation chains hide the 40-cycle dependent latency of the 16x16x4 MFMA; the next group's
         // operands -- across unit boundaries too -- are read while the current four steps multiply.
         // (Running a unit's epilogue under the first MFMAs of the next unit was measured slower: 1.15 vs 1.08 ms.)
+        float tile_min = 3.0e38f;
         int4v d = desc[0];                                          // {kstart, nsteps, aoff, mt | ft << 8}
         int ks = __builtin_amdgcn_readfirstlane(d.x), ns = __builtin_amdgcn_readfirstlane(d.y);
         int ao = __builtin_amdgcn_readfirstlane(d.z), code = __builtin_amdgcn_readfirstlane(d.w);
@@ -370,6 +419,8 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
             bv = bn;
             acc += acc2;
             STAMP(9);
+            // (Swapping the operand roles so that a lane holds 4 consecutive frames and stores 16 bytes was
+            // measured 2 % slower than these four dword stores.)
             const int fl = ft * 16 + (lane & 15);                  // frame within the tile
             const int mel0 = mt * 16 + (lane >> 4) * 4;
             const unsigned o0 = (unsigned)(mel0 * n_frames + t0 + fl);
@@ -385,7 +436,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     run_max = fmaxf(run_max, mv[r]);
-                    run_min = fminf(run_min, mv[r]);
+                    tile_min = fminf(tile_min, mv[r]);
                     out_clip[o0 + (unsigned)(r * n_frames)] = yv[r];
                 }
             } else {
@@ -395,13 +446,17 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
                 for (int r = 0; r < 4; ++r) {
                     if (mel0 + r < n_mels && t0 + fl < n_frames) {
                         run_max = fmaxf(run_max, mv[r]);
-                        run_min = fminf(run_min, mv[r]);
+                        tile_min = fminf(tile_min, mv[r]);
                         out_clip[o0 + (unsigned)(r * n_frames)] = (tmasked || ((mbits >> r) & 1u)) ? 0.0f : yv[r];
                     }
                 }
             }
             STAMP(1);
         }
+        // per-tile minimum (kernel 2 re-reads only the tiles that hold something below max - 8)
+        tile_min = wave_min(tile_min);
+        if (lane == 0 && tile_min < 1.0e38f)
+            atomicMax(&keys[(size_t)clip * kKeysPerClip + 1 + tile], ~float_to_key(__log2f(tile_min) * 0.30102999566398120f));
         STAMP(7);
         __syncthreads();      // panel reads done before the next tile's slab writes
         STAMP(8);
@@ -416,26 +471,23 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         run_max = fmaxf(run_max, __shfl_xor(run_max, off, 64));
-        run_min = fminf(run_min, __shfl_xor(run_min, off, 64));
     }
-    if (lane == 0 && run_max > 0.0f) {
+    if (lane == 0 && run_max > 0.0f)
         atomicMax(&keys[(size_t)clip * kKeysPerClip], float_to_key(__log2f(run_max) * 0.30102999566398120f));
-        atomicMax(&keys[(size_t)clip * kKeysPerClip + 1 + blockIdx.x], ~float_to_key(__log2f(run_min) * 0.30102999566398120f));
-    }
 }
 
-// Clamp / fill pass.  grid.x = n_runs + kFillBlocks, grid.y = clips.
-//   x <  n_runs : the run of tiles one kernel-1 workgroup walked: re-read and clamp to (max - 8 + 4) / 4
-//                 only when the run's recorded minimum is below max - 8 (otherwise exit at once);
-//   x >= n_runs : fill role: mel rows x - n_runs, + kFillBlocks, ... of the clip's zero-padding region
-//                 [first padding frame, n_frames) get the final constant with full-row vector stores.
+// Clamp / fill pass.  grid.x = kRowSplit, grid.y = clips: workgroup x owns mel rows x, x + kRowSplit, ... of its clip.
+//   fill : the clip's zero-padding region [first padding frame, n_frames) gets the final constant with full-row
+//          vector stores (kernel 1 never touches it);
+//   clamp: of the computed tiles only those whose recorded minimum is below max - 8 (a few per cent of the tiles of
+//          ordinary audio; none for most clips) are re-read and clamped to (max - 8 + 4) / 4.
 // SpecAugment masks -> 0.0 on everything written.
 __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     float* __restrict__ out, const int32_t* __restrict__ lengths, const unsigned* __restrict__ keys,
-    int n_mels, int n_frames, const int32_t* __restrict__ mask_tbl, int n_masks, int tiles_per_block, int n_runs) {
+    int n_mels, int n_frames, const int32_t* __restrict__ mask_tbl, int n_masks) {
     using namespace wh;
-    const int kFillBlocks = gridDim.x - n_runs;
     const int clip = blockIdx.y;
+    const int row0 = blockIdx.x, row_step = gridDim.x;
     int n_valid = lengths[clip];
     n_valid = n_valid < 0 ? 0 : (n_valid > kMaxSamples ? kMaxSamples : n_valid);
     const int n_tiles = (n_frames + kTileFrames - 1) / kTileFrames;
@@ -445,27 +497,23 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     const float lmax = kmax ? key_to_float(kmax) : -10.0f;        // no computed tile at all: log10(1e-10)
     const float floor_lg = lmax - 8.0f;
     const float floor_y = (floor_lg + 4.0f) * 0.25f;
-    int f_begin, f_end, row0, row_step;
-    bool fill;
-    if ((int)blockIdx.x < n_runs) {
-        const int t_begin = blockIdx.x * tiles_per_block;
-        f_begin = t_begin * kTileFrames;
-        f_end = min(pad_frame, (t_begin + tiles_per_block) * kTileFrames);
-        if (f_begin >= f_end) return;
-        const unsigned kmin = ~keys[(size_t)clip * kKeysPerClip + 1 + blockIdx.x];
-        if (key_to_float(kmin) >= floor_lg) return;               // nothing in this run is below the floor
-        fill = false;
-        row0 = 0;
-        row_step = 1;
-    } else {
-        f_begin = pad_frame;
-        f_end = n_frames;
-        if (f_begin >= f_end) return;
-        fill = true;
-        row0 = blockIdx.x - n_runs;
-        row_step = kFillBlocks;
-    }
     const float pad_y = fmaxf((-10.0f + 4.0f) * 0.25f, floor_y);
+
+    // tiles of the clip with something below the floor (n_tiles <= 63: one 64-bit word)
+    __shared__ unsigned long long s_flags;
+    if (threadIdx.x < 64) {
+        bool flag = false;
+        if ((int)threadIdx.x < first_pad_tile) {
+            const unsigned kmin = ~keys[(size_t)clip * kKeysPerClip + 1 + threadIdx.x];
+            flag = key_to_float(kmin) < floor_lg;
+        }
+        const unsigned long long bal = __ballot(flag);
+        if (threadIdx.x == 0) s_flags = bal;
+    }
+    __syncthreads();
+    const unsigned long long flags = s_flags;
+    if (pad_frame >= n_frames && flags == 0ull) return;           // the usual full-length clip: nothing to do
+
     const int32_t* __restrict__ cm = mask_tbl ? mask_tbl + (size_t)clip * n_masks * 3 : nullptr;
     const int nm = cm ? n_masks : 0;
     const uint64_t melmask_lo = mask_bits(cm, nm, STTFE_AXIS_FREQ, 0, 64);
@@ -478,48 +526,79 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
             ++nt;
         }
     float* __restrict__ o = out + (size_t)clip * n_mels * n_frames;
-    // rows are n_frames floats long, n_frames % 4 == 0, f_begin % 4 == 0 (tile starts): float4 accesses are aligned
-    const int quads = (f_end - f_begin) >> 2;
-    if (fill) {
-        // constant rows with plain vector stores, then the few time-masked columns are zeroed
+    const int rows = (n_mels - row0 + row_step - 1) / row_step;
+
+    // ---- fill: rows are n_frames floats long, n_frames % 4 == 0, pad_frame % 4 == 0: aligned 16-byte stores
+    if (pad_frame < n_frames) {
+        const int quads = (n_frames - pad_frame) >> 2;
         for (int mel = row0; mel < n_mels; mel += row_step) {
             const bool mmasked = ((mel < 64 ? melmask_lo >> mel : melmask_hi >> (mel - 64)) & 1ull);
             const float c = mmasked ? 0.0f : pad_y;
             const f32x4 c4 = {c, c, c, c};
-            f32x4* rowp = reinterpret_cast<f32x4*>(o + (size_t)mel * n_frames + f_begin);
+            f32x4* rowp = reinterpret_cast<f32x4*>(o + (size_t)mel * n_frames + pad_frame);
             for (int q = threadIdx.x; q < quads; q += blockDim.x) rowp[q] = c4;
         }
-        if (nt == 0) return;
-        __syncthreads();
-        for (int i = 0; i < nt; ++i) {
-            const int a = max(ts[i], f_begin), w = min(te[i], f_end) - a;
-            if (w <= 0) continue;
-            const int rows = (n_mels - row0 + row_step - 1) / row_step;
-            for (int e = threadIdx.x; e < rows * w; e += blockDim.x) {
-                const int r = e / w, c = e - r * w;
-                o[(size_t)(row0 + r * row_step) * n_frames + a + c] = 0.0f;
+        if (nt != 0) {                                             // then the few time-masked columns are zeroed
+            __syncthreads();
+            for (int i = 0; i < nt; ++i) {
+                const int a = max(ts[i], pad_frame), w = min(te[i], n_frames) - a;
+                if (w <= 0) continue;
+                for (int e = threadIdx.x; e < rows * w; e += blockDim.x) {
+                    const int r = e / w, c = e - r * w;
+                    o[(size_t)(row0 + r * row_step) * n_frames + a + c] = 0.0f;
+                }
             }
         }
-        return;
     }
-    for (int mel = row0; mel < n_mels; mel += row_step) {
-        const bool mmasked = ((mel < 64 ? melmask_lo >> mel : melmask_hi >> (mel - 64)) & 1ull);
-        f32x4* rowp = reinterpret_cast<f32x4*>(o + (size_t)mel * n_frames + f_begin);
-        for (int q = threadIdx.x; q < quads; q += blockDim.x) {
-            const f32x4 v = rowp[q];
+    if (flags == 0ull) return;
+
+    // ---- clamp: (flagged tile, row, 4-frame quad) items are dealt round-robin to the threads; a thread loads up to
+    // kBatch items before its first store (the compiler cannot move a load above a store to the same array, and
+    // one HBM round trip per item would make the pass latency-bound).
+    __shared__ unsigned char s_tiles[64];
+    const int n_flagged = __popcll(flags);
+    if (threadIdx.x < 64 && ((flags >> threadIdx.x) & 1ull))
+        s_tiles[__popcll(flags & ((1ull << threadIdx.x) - 1ull))] = (unsigned char)threadIdx.x;
+    __syncthreads();
+    constexpr int kBatch = 4;
+    constexpr int kQuadsPerTile = kTileFrames / 4;                 // 12
+    const int per_tile = rows * kQuadsPerTile, n_items = n_flagged * per_tile;
+    for (int base = threadIdx.x; base < n_items; base += kBatch * blockDim.x) {
+        int fr0[kBatch], melv[kBatch];
+        f32x4 v[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+            const int item = base + i * blockDim.x;
+            fr0[i] = -1;
+            if (item < n_items) {
+                const int ti = item / per_tile, rem = item - ti * per_tile;
+                const int r = rem / kQuadsPerTile, qt = rem - r * kQuadsPerTile;
+                const int fr = s_tiles[ti] * kTileFrames + 4 * qt;
+                melv[i] = row0 + r * row_step;
+                if (fr < pad_frame) {                              // pad_frame is a multiple of 4
+                    fr0[i] = fr;
+                    v[i] = *reinterpret_cast<const f32x4*>(o + (size_t)melv[i] * n_frames + fr);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+            if (fr0[i] < 0) continue;
+            const int mel = melv[i];
+            const bool mmasked = ((mel < 64 ? melmask_lo >> mel : melmask_hi >> (mel - 64)) & 1ull);
             f32x4 w;
             bool changed = false;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float y = fmaxf(v[c], floor_y);
-                const int fr = f_begin + 4 * q + c;
+                float y = fmaxf(v[i][c], floor_y);
+                const int fr = fr0[i] + c;
                 bool masked = mmasked;                             // masked cells of a computed tile already hold 0.0
-                for (int i = 0; i < nt; ++i) masked |= (fr >= ts[i] && fr < te[i]);
+                for (int m = 0; m < nt; ++m) masked |= (fr >= ts[m] && fr < te[m]);
                 if (masked) y = 0.0f;
-                changed |= (y != v[c]);
+                changed |= (y != v[i][c]);
                 w[c] = y;
             }
-            if (changed) rowp[q] = w;
+            if (changed) *reinterpret_cast<f32x4*>(o + (size_t)mel * n_frames + fr0[i]) = w;
         }
     }
 }
@@ -558,6 +637,7 @@ extern "C" int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, co
         return STTFE_E_INVALID_ARG;
     if (batch == 0) return STTFE_OK;
     if (!pcm || !offsets || !lengths || !dev_tables || !out || !workspace) return STTFE_E_INVALID_ARG;
+    if (reinterpret_cast<uintptr_t>(out) & 15) return STTFE_E_INVALID_ARG;      // rows are written as 16-byte vectors
     if ((size_t)wh::kHop * (size_t)n_frames > (size_t)wh::kMaxSamples || batch > 65535) return STTFE_E_UNSUPPORTED;
     size_t need = 0;
     sttfe_whisper_workspace_bytes(batch, &need);
@@ -594,13 +674,13 @@ extern "C" int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, co
     }
     {
         ScopedTiming t(kTimeWhisperClamp, stream);
-        static const int fill_blocks = [] {
-            const char* e = getenv("STTFE_FILL_BLOCKS");          // tuning knob (default 8)
+        static const int row_split = [] {
+            const char* e = getenv("STTFE_ROW_SPLIT");            // tuning knob (default 8 workgroups per clip)
             const int v = e ? atoi(e) : 8;
             return v < 1 ? 1 : (v > 128 ? 128 : v);
         }();
-        hipLaunchKernelGGL(whisper_clamp_fill_kernel, dim3(blocks_x + fill_blocks, batch), dim3(256), 0, stream, out,
-                           lengths, keys, n_mels, n_frames, mask_tbl, n_masks, tiles_per_block, blocks_x);
+        hipLaunchKernelGGL(whisper_clamp_fill_kernel, dim3(row_split, batch), dim3(256), 0, stream, out, lengths, keys,
+                           n_mels, n_frames, mask_tbl, n_masks);
     }
     if (hip_failed(hipGetLastError(), "whisper kernel launch")) return STTFE_E_LAUNCH;
     return STTFE_OK;
