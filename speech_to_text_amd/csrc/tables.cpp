@@ -137,6 +137,14 @@ void build_mel_plan(const std::vector<float>& dense, int n_mels, int n_bins, flo
         plan.wave_units[best][plan.wave_nunits[best]++] = u.mt | (u.ft << 8);
         load[best] += u.cost;
     }
+    for (int w = 0; w < n_waves; ++w)
+        for (int u = 0; u < plan.wave_nunits[w]; ++u) {
+            const int code = plan.wave_units[w][u], mt = code & 0xff;
+            plan.desc[w][u][0] = plan.kstart[mt];
+            plan.desc[w][u][1] = plan.nsteps[mt];
+            plan.desc[w][u][2] = plan.aoff[mt];
+            plan.desc[w][u][3] = code;
+        }
 }
 
 }  // namespace sttfe

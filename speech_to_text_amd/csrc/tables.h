@@ -26,7 +26,11 @@ struct MelPlan {
     int32_t aoff[kMaxMelTiles];                       // float offset into afrag
     int32_t wave_nunits[kWavesPerBlock];
     int32_t wave_units[kWavesPerBlock][kMaxUnitsPerWave];   // mt | (ft << 8)
+    // the same plan as ready-made unit descriptors {kstart, nsteps, aoff, mt | ft << 8} (zeros past wave_nunits):
+    // a kernel stages them with one 16-byte load per unit instead of two dependent table look-ups
+    int32_t desc[kWavesPerBlock][kMaxUnitsPerWave][4];
 };
+static_assert(sizeof(MelPlan) % 16 == 0, "descriptors are read as 16-byte words");
 
 struct KaldiTablesHeader {
     uint32_t magic;

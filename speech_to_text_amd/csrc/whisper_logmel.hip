@@ -27,7 +27,7 @@
 //     applied from per-tile / per-clip bit masks; per-clip max and per-tile min of log10 go to the
 //     workspace with one atomic per wave.
 //   Tiles that lie entirely in the 30 s zero padding are left to kernel 2 (they are constant).
-// Kernel 2 (clamp_fill): 8 workgroups per clip, each owning every 8th mel row.  The zero-padding region is filled
+// Kernel 2 (clamp_fill): 16-32 workgroups per clip, each owning 4-5 interleaved mel rows.  The zero-padding region is filled
 //   with the final constant (write only); of the computed tiles only those whose recorded minimum is below
 //   max - 8 are re-read and clamped to (max - 8 + 4) / 4 (everything else is already final).
 #include <hip/hip_runtime.h>
@@ -167,51 +167,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     tile_end = min(tile_end, first_pad_tile);
     if (tile_begin >= tile_end) return;
 
-    // zero the slabs once (pad cells are read by zero-weight MFMA steps and must be finite), stage tables
-    for (int i = tid; i < kWinOff; i += kThreads) smem[i] = 0.f;
-    // window as [j][n1] and twiddles W400^(j k1) as [j][k1]: each lane reads its 20 values as b128 words
-    for (int i = tid; i < 400; i += kThreads) smem[kWinOff + (i % 20) * 20 + i / 20] = tab->window[i];
-    for (int i = tid; i < 800; i += kThreads) {
-        const int c = i >> 1, k1 = c / 20, jj = c - 20 * k1;
-        smem[kTwOff + jj * kTwStride + 2 * k1 + (i & 1)] = tab->twiddle[i];
-    }
-    {
-        const float* __restrict__ afrag_g = reinterpret_cast<const float*>(tab + 1);
-        const int na = min(tab->afrag_floats, kMaxAfragFloats);
-        for (int i = tid; i < na; i += kThreads) smem[kAfragOff + i] = afrag_g[i];
-        int* desc = reinterpret_cast<int*>(smem + kDescOff);
-        if (tid < kWaves * kMaxUnitsPerWave) {
-            const int w = tid / kMaxUnitsPerWave, u = tid - w * kMaxUnitsPerWave;
-            const int code = tab->plan.wave_units[w][u], mt = code & 0xff;
-            const bool ok = u < tab->plan.wave_nunits[w];
-            desc[4 * tid + 0] = ok ? tab->plan.kstart[mt] : 0;
-            desc[4 * tid + 1] = ok ? tab->plan.nsteps[mt] : 0;
-            desc[4 * tid + 2] = ok ? tab->plan.aoff[mt] : 0;
-            desc[4 * tid + 3] = code;
-        }
-        if (tid < kWaves) desc[4 * kWaves * kMaxUnitsPerWave + tid] = tab->plan.wave_nunits[tid];
-    }
-    __syncthreads();
-
     const float* __restrict__ x = pcm + offsets[clip];
-    float* __restrict__ out_clip = out + (size_t)clip * n_mels * n_frames;
-    const float* afrag = smem + kAfragOff;
-    const int4v* desc = reinterpret_cast<const int4v*>(smem + kDescOff) + wave * kMaxUnitsPerWave;
-    const int nu = __builtin_amdgcn_readfirstlane(
-        reinterpret_cast<const int*>(smem + kDescOff)[4 * kWaves * kMaxUnitsPerWave + wave]);
-    const int partner = active ? (p * 20 + ((20 - j) % 20)) : lane;
-    float* my_rows = smem + wave * kSlabFloats;
-    f2* slab_w = reinterpret_cast<f2*>(my_rows) + pa_ * kPairStride + j;                        // stage-1 writes: [k1][n2 = j]
-    const f32x4* slab_r = reinterpret_cast<const f32x4*>(my_rows + 2 * (pa_ * kPairStride + j * kRowStride));   // row k1 = j
-    const f32x4* win4 = reinterpret_cast<const f32x4*>(smem + kWinOff + 20 * j);
-    const f32x4* tw4 = reinterpret_cast<const f32x4*>(smem + kTwOff + kTwStride * j);
-
-    // SpecAugment: mel-axis masks as two 64-bit words for the clip; time-axis masks per tile
-    const int32_t* __restrict__ clip_masks = mask_tbl ? mask_tbl + (size_t)clip * n_masks * 3 : nullptr;
-    const int nm = clip_masks ? n_masks : 0;
-    const uint64_t melmask_lo = mask_bits(clip_masks, nm, STTFE_AXIS_FREQ, 0, 64);
-    const uint64_t melmask_hi = mask_bits(clip_masks, nm, STTFE_AXIS_FREQ, 64, 64);
-
     // 28 samples per lane and pass: frame a = rows 0..19, frame b = rows 8..27 of x[base + 20 m]
     auto load_pass = [&](int t0, int pass, float (&r)[28]) {
         const int f0 = t0 + wave * kFramesPerWave + 6 * pass;          // first frame of the pass (wave-uniform)
@@ -235,6 +191,48 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
             }
         }
     };
+
+    // PCM of the first tile: requested before the tables are staged, so that its HBM latency overlaps the staging
+    float raw0[28], raw1[28];                      // the two passes of the NEXT tile, loaded a whole tile ahead
+    load_pass(tile_begin * kTileFrames, 0, raw0);
+    load_pass(tile_begin * kTileFrames, 1, raw1);
+
+    // zero the slabs once (pad cells are read by zero-weight MFMA steps and must be finite), stage tables
+    for (int i = tid; i < kWinOff; i += kThreads) smem[i] = 0.f;
+    // window as [j][n1] and twiddles W400^(j k1) as [j][k1]: each lane reads its 20 values as b128 words
+    for (int i = tid; i < 400; i += kThreads) smem[kWinOff + (i % 20) * 20 + i / 20] = tab->window[i];
+    for (int i = tid; i < 800; i += kThreads) {
+        const int c = i >> 1, k1 = c / 20, jj = c - 20 * k1;
+        smem[kTwOff + jj * kTwStride + 2 * k1 + (i & 1)] = tab->twiddle[i];
+    }
+    {
+        const float* __restrict__ afrag_g = reinterpret_cast<const float*>(tab + 1);
+        const int na = min(tab->afrag_floats, kMaxAfragFloats);
+        for (int i = tid; i < na; i += kThreads) smem[kAfragOff + i] = afrag_g[i];
+        int* desc = reinterpret_cast<int*>(smem + kDescOff);
+        if (tid < kWaves * kMaxUnitsPerWave)
+            reinterpret_cast<int4v*>(desc)[tid] = reinterpret_cast<const int4v*>(&tab->plan.desc[0][0][0])[tid];
+        if (tid < kWaves) desc[4 * kWaves * kMaxUnitsPerWave + tid] = tab->plan.wave_nunits[tid];
+    }
+    __syncthreads();
+
+    float* __restrict__ out_clip = out + (size_t)clip * n_mels * n_frames;
+    const float* afrag = smem + kAfragOff;
+    const int4v* desc = reinterpret_cast<const int4v*>(smem + kDescOff) + wave * kMaxUnitsPerWave;
+    const int nu = __builtin_amdgcn_readfirstlane(
+        reinterpret_cast<const int*>(smem + kDescOff)[4 * kWaves * kMaxUnitsPerWave + wave]);
+    const int partner = active ? (p * 20 + ((20 - j) % 20)) : lane;
+    float* my_rows = smem + wave * kSlabFloats;
+    f2* slab_w = reinterpret_cast<f2*>(my_rows) + pa_ * kPairStride + j;                        // stage-1 writes: [k1][n2 = j]
+    const f32x4* slab_r = reinterpret_cast<const f32x4*>(my_rows + 2 * (pa_ * kPairStride + j * kRowStride));   // row k1 = j
+    const f32x4* win4 = reinterpret_cast<const f32x4*>(smem + kWinOff + 20 * j);
+    const f32x4* tw4 = reinterpret_cast<const f32x4*>(smem + kTwOff + kTwStride * j);
+
+    // SpecAugment: mel-axis masks as two 64-bit words for the clip; time-axis masks per tile
+    const int32_t* __restrict__ clip_masks = mask_tbl ? mask_tbl + (size_t)clip * n_masks * 3 : nullptr;
+    const int nm = clip_masks ? n_masks : 0;
+    const uint64_t melmask_lo = mask_bits(clip_masks, nm, STTFE_AXIS_FREQ, 0, 64);
+    const uint64_t melmask_hi = mask_bits(clip_masks, nm, STTFE_AXIS_FREQ, 64, 64);
 
     // Window and twiddles of this lane stay in registers for the whole tile run (60 VGPRs).
     f32x4 w4[5], t4[10];
@@ -330,9 +328,6 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         return fw * kSlabFloats + (fl - fw * kFramesPerWave) * kPStride + 4 * (lane >> 4);
     };
     const int brow0 = b_row(0), brow1 = b_row(1), brow2 = b_row(2);
-    float raw0[28], raw1[28];                      // the two passes of the NEXT tile, loaded a whole tile ahead
-    load_pass(tile_begin * kTileFrames, 0, raw0);
-    load_pass(tile_begin * kTileFrames, 1, raw1);
 #ifdef STTFE_STAMPS
     unsigned long long stamp_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
@@ -476,7 +471,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         atomicMax(&keys[(size_t)clip * kKeysPerClip], float_to_key(__log2f(run_max) * 0.30102999566398120f));
 }
 
-// Clamp / fill pass.  grid.x = kRowSplit, grid.y = clips: workgroup x owns mel rows x, x + kRowSplit, ... of its clip.
+// Clamp / fill pass.  grid.x = row split, grid.y = clips: workgroup x owns mel rows x, x + gridDim.x, ... of its clip.
 //   fill : the clip's zero-padding region [first padding frame, n_frames) gets the final constant with full-row
 //          vector stores (kernel 1 never touches it);
 //   clamp: of the computed tiles only those whose recorded minimum is below max - 8 (a few per cent of the tiles of
@@ -648,7 +643,12 @@ extern "C" int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, co
     if (hip_failed(hipMemsetAsync(keys, 0, need, stream), "hipMemsetAsync(keys)")) return STTFE_E_LAUNCH;
 
     const int n_tiles = (n_frames + wh::kTileFrames - 1) / wh::kTileFrames;
-    int tiles_per_block = g_whisper_tiles_per_block;
+    static const int tpb_env = [] {
+        const char* e = getenv("STTFE_WH_TILES_PER_BLOCK");       // tuning knob, as sttfe_set_whisper_tiles_per_block
+        const int v = e ? atoi(e) : 0;
+        return v < 0 || v > wh::kMaxTiles ? 0 : v;
+    }();
+    int tiles_per_block = g_whisper_tiles_per_block ? g_whisper_tiles_per_block : tpb_env;
     if (tiles_per_block == 0) {
         // two 4-wave workgroups per CU, 256 CUs: aim for >= 2 rounds of workgroups, runs as long as possible
         const int choices[5] = {21, 9, 7, 5, 3};
@@ -674,11 +674,13 @@ extern "C" int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, co
     }
     {
         ScopedTiming t(kTimeWhisperClamp, stream);
-        static const int row_split = [] {
-            const char* e = getenv("STTFE_ROW_SPLIT");            // tuning knob (default 8 workgroups per clip)
-            const int v = e ? atoi(e) : 8;
-            return v < 1 ? 1 : (v > 128 ? 128 : v);
+        // 4-5 mel rows per workgroup measured best for the fill (4.3 TB/s) without slowing the full-length case
+        static const int row_split_env = [] {
+            const char* e = getenv("STTFE_ROW_SPLIT");            // tuning knob (0 / unset = automatic)
+            const int v = e ? atoi(e) : 0;
+            return v < 0 ? 0 : (v > 128 ? 128 : v);
         }();
+        const int row_split = row_split_env ? row_split_env : (n_mels > 96 ? (n_mels + 3) / 4 : (n_mels + 4) / 5);
         hipLaunchKernelGGL(whisper_clamp_fill_kernel, dim3(row_split, batch), dim3(256), 0, stream, out, lengths, keys,
                            n_mels, n_frames, mask_tbl, n_masks);
     }
