@@ -68,7 +68,9 @@ constexpr int kTwOff = kWinOff + 400;
 constexpr int kAfragOff = kTwOff + 20 * kTwStride;               // banded mel weights in MFMA A-operand order
 constexpr int kMaxAfragFloats = 4608;                 // 53 (80 mels) / 56 (128 mels) k-steps x 64 lanes
 constexpr int kDescOff = kAfragOff + kMaxAfragFloats;     // per wave: 8 x {kstart, nsteps, aoff, mt | ft << 8}, then the unit counts
-constexpr int kLdsFloats = kDescOff + kWaves * kMaxUnitsPerWave * 4 + kWaves;   // 62032 B -> 2 workgroups per CU
+constexpr int kTicketOff = kDescOff + kWaves * kMaxUnitsPerWave * 4 + kWaves;    // 3 words: work-item hand-over slots
+constexpr int kMaskOff = kTicketOff + 4;              // the current clip's SpecAugment masks: 8 x {axis, start, end}
+constexpr int kLdsFloats = kMaskOff + 24;   // 62032 B -> 2 workgroups per CU
 }  // namespace wh
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -109,7 +111,7 @@ __device__ __forceinline__ float wave_min(float v) {
 }
 
 // Bits [0, width) of the result mark the indices base + i covered by a mask of the given axis.
-__device__ __forceinline__ uint64_t mask_bits(const int32_t* __restrict__ m, int n_masks, int axis, int base, int width) {
+__device__ __forceinline__ uint64_t mask_bits(const int32_t* m, int n_masks, int axis, int base, int width) {
     uint64_t bits = 0;
     for (int i = 0; i < n_masks; ++i) {
         if (m[3 * i] != axis) continue;
@@ -144,11 +146,11 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     const float* __restrict__ pcm, const int64_t* __restrict__ offsets,
     const int32_t* __restrict__ lengths, int n_mels, int n_frames,
     const WhisperTablesHeader* __restrict__ tab, float* __restrict__ out,
-    unsigned* __restrict__ keys, const int32_t* __restrict__ mask_tbl, int n_masks, int tiles_per_block) {
+    unsigned* __restrict__ keys, const int32_t* __restrict__ mask_tbl, int n_masks, int tiles_per_block,
+    int batch, unsigned* __restrict__ ticket) {
     using namespace wh;
     __shared__ __attribute__((aligned(16))) float smem[kLdsFloats];
 
-    const int clip = blockIdx.y;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -157,30 +159,74 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     const bool active = lane < 60;
     const int pa_ = active ? p : 0;
 
-    int n_valid = lengths[clip];
-    n_valid = n_valid < 0 ? 0 : (n_valid > kMaxSamples ? kMaxSamples : n_valid);
+    // Work items are (tile run, clip) pairs, run-major: item = run * batch + clip, for the runs that the longest clip
+    // of the batch reaches.  A workgroup stages the tables once and then takes items from a ticket counter in the
+    // workspace (zeroed by the host): the first item is blockIdx.x, every further one gridDim.x + atomicAdd(ticket).
+    // Thread 0 requests the ticket two items ahead and publishes it through LDS at the end of an item, so that the
+    // atomic, the length / offset of the next item and its first PCM tile are all in flight under useful work.
+    // Every workgroup leaves its loop after at most n_items tickets; all threads of a workgroup take the same path.
     const int n_tiles = (n_frames + kTileFrames - 1) / kTileFrames;
-    const int tile_begin = blockIdx.x * tiles_per_block;
-    int tile_end = min(tile_begin + tiles_per_block, n_tiles);
-    // tiles whose first sample lies in the zero padding are constant: kernel 2 fills them
-    const int first_pad_tile = (n_valid + kNfft / 2 + kHop * kTileFrames - 1) / (kHop * kTileFrames);
-    tile_end = min(tile_end, first_pad_tile);
-    if (tile_begin >= tile_end) return;
+    auto clamp_len = [](int n) { return n < 0 ? 0 : (n > kMaxSamples ? kMaxSamples : n); };
+    // first tile that lies entirely in the zero padding (those are constant: kernel 2 fills them)
+    auto first_pad_tile_of = [](int n_valid) { return (n_valid + kNfft / 2 + kHop * kTileFrames - 1) / (kHop * kTileFrames); };
+    unsigned my_ticket = 0;
+    if (tid == 0) my_ticket = atomicAdd(ticket, 1u);               // -> the workgroup's second item
+    // longest and shortest clip of the batch (every workgroup computes the same values; skipped for very large batches)
+    int max_len = kMaxSamples, min_len = 0;
+    if (batch <= 16384) {
+        int m = 0, mn = kMaxSamples;
+        for (int i = tid; i < batch; i += kThreads) {
+            const int l = clamp_len(lengths[i]);
+            m = max(m, l);
+            mn = min(mn, l);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            m = max(m, __shfl_xor(m, off, 64));
+            mn = min(mn, __shfl_xor(mn, off, 64));
+        }
+        if (lane == 0) {                                           // the slabs are zeroed after the barrier below
+            reinterpret_cast<int*>(smem)[wave] = m;
+            reinterpret_cast<int*>(smem)[kWaves + wave] = mn;
+        }
+        __syncthreads();
+        max_len = 0;
+        min_len = kMaxSamples;
+        for (int w = 0; w < kWaves; ++w) {
+            max_len = max(max_len, reinterpret_cast<const int*>(smem)[w]);
+            min_len = min(min_len, reinterpret_cast<const int*>(smem)[kWaves + w]);
+        }
+        __syncthreads();
+    }
+    // Run length (tiles per item).  Long runs are measured faster per tile (1.03 ms at 21 tiles against 1.22 ms at 7
+    // for 1024 full-length clips), short ones keep the workgroups balanced when clip lengths differ: a third of the
+    // clip for (near-)uniform batches, a fifth of the longest clip otherwise.
+    const int max_tiles = min(n_tiles, first_pad_tile_of(max_len));
+    if (tiles_per_block <= 0) {
+        const bool uniform = first_pad_tile_of(min_len) + 1 >= max_tiles;
+        tiles_per_block = uniform ? (max_tiles + 2) / 3 : (max_tiles + 4) / 5;
+        tiles_per_block = max(3, min(21, tiles_per_block));
+    }
+    tiles_per_block = __builtin_amdgcn_readfirstlane(tiles_per_block);
+    const int n_runs = (max_tiles + tiles_per_block - 1) / tiles_per_block;
+    const int n_items = n_runs * batch;
+    int item = blockIdx.x, next_item = 0;
+    if (item >= n_items) return;
+    // length / offset of the current item and of the next one (requested one item ahead)
+    int len_cur = lengths[item % batch];
+    int64_t off_cur = offsets[item % batch];
+    int len_next = 0;
+    int64_t off_next = 0;
+    unsigned iter = 0;
 
-    const float* __restrict__ x = pcm + offsets[clip];
     // 28 samples per lane and pass: frame a = rows 0..19, frame b = rows 8..27 of x[base + 20 m]
-    auto load_pass = [&](int t0, int pass, float (&r)[28]) {
+    auto load_pass = [&](const float* __restrict__ x, int n_valid, int t0, int pass, float (&r)[28]) {
         const int f0 = t0 + wave * kFramesPerWave + 6 * pass;          // first frame of the pass (wave-uniform)
         const int first = kHop * f0 - kNfft / 2;
         const int base = first + 2 * kHop * pa_ + j;
         if (first >= 0 && first + 5 * kHop + kNfft <= n_valid) {
-#ifdef ABL_NOLOAD
-#pragma unroll
-            for (int m = 0; m < 28; ++m) r[m] = (float)(base + m) * 1e-7f;
-#else
 #pragma unroll
             for (int m = 0; m < 28; ++m) r[m] = x[base + 20 * m];
-#endif
         } else {
 #pragma unroll
             for (int m = 0; m < 28; ++m) {
@@ -191,11 +237,8 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
             }
         }
     };
-
-    // PCM of the first tile: requested before the tables are staged, so that its HBM latency overlaps the staging
     float raw0[28], raw1[28];                      // the two passes of the NEXT tile, loaded a whole tile ahead
-    load_pass(tile_begin * kTileFrames, 0, raw0);
-    load_pass(tile_begin * kTileFrames, 1, raw1);
+    bool raw_ready = false;                        // raw0 / raw1 already hold the first tile of the current item
 
     // zero the slabs once (pad cells are read by zero-weight MFMA steps and must be finite), stage tables
     for (int i = tid; i < kWinOff; i += kThreads) smem[i] = 0.f;
@@ -213,10 +256,11 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         if (tid < kWaves * kMaxUnitsPerWave)
             reinterpret_cast<int4v*>(desc)[tid] = reinterpret_cast<const int4v*>(&tab->plan.desc[0][0][0])[tid];
         if (tid < kWaves) desc[4 * kWaves * kMaxUnitsPerWave + tid] = tab->plan.wave_nunits[tid];
+        if (tid == 0) reinterpret_cast<unsigned*>(smem + kTicketOff)[0] = my_ticket + gridDim.x;
     }
     __syncthreads();
+    next_item = (int)min(reinterpret_cast<const unsigned*>(smem + kTicketOff)[0], (unsigned)n_items);
 
-    float* __restrict__ out_clip = out + (size_t)clip * n_mels * n_frames;
     const float* afrag = smem + kAfragOff;
     const int4v* desc = reinterpret_cast<const int4v*>(smem + kDescOff) + wave * kMaxUnitsPerWave;
     const int nu = __builtin_amdgcn_readfirstlane(
@@ -228,16 +272,9 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     const f32x4* win4 = reinterpret_cast<const f32x4*>(smem + kWinOff + 20 * j);
     const f32x4* tw4 = reinterpret_cast<const f32x4*>(smem + kTwOff + kTwStride * j);
 
-    // SpecAugment: mel-axis masks as two 64-bit words for the clip; time-axis masks per tile
-    const int32_t* __restrict__ clip_masks = mask_tbl ? mask_tbl + (size_t)clip * n_masks * 3 : nullptr;
-    const int nm = clip_masks ? n_masks : 0;
-    const uint64_t melmask_lo = mask_bits(clip_masks, nm, STTFE_AXIS_FREQ, 0, 64);
-    const uint64_t melmask_hi = mask_bits(clip_masks, nm, STTFE_AXIS_FREQ, 64, 64);
 
-    // Window and twiddles of this lane stay in registers for the whole tile run (60 VGPRs).
-    f32x4 w4[5], t4[10];
-#pragma unroll
-    for (int q = 0; q < 5; ++q) w4[q] = win4[q];
+    // The twiddles of this lane stay in registers for the whole kernel (40 VGPRs).
+    f32x4 t4[10];
 #pragma unroll
     for (int q = 0; q < 10; ++q) t4[q] = tw4[q];
 
@@ -251,6 +288,9 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     //   sep_*    : partner lane's Z[400 - k] by ds_bpermute, then 4 |A|^2, 4 |B|^2 for bins j + 20 k2
     auto s1_math = [&](const float (&raw)[28], f2 (&y)[20]) {
         f2 v[20];
+        f32x4 w4[5];                                               // window of this lane: 5 b128 reads per pass
+#pragma unroll
+        for (int q = 0; q < 5; ++q) w4[q] = win4[q];
 #pragma unroll
         for (int i = 0; i < 20; ++i) {
             const float w = w4[i >> 2][i & 3];
@@ -316,12 +356,6 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         }
     };
 
-#ifdef EXP_DEPHASE
-    if ((blockIdx.x + blockIdx.y) & 1) {
-        for (int i = 0; i < EXP_DEPHASE; ++i) __builtin_amdgcn_s_sleep(127);     // ~127 * 64 cycles each
-    }
-#endif
-    float run_max = 0.0f;                           // mel energies (>= 1e-10 once any cell was produced)
     // LDS float offset of this lane's B-operand row (frame ft * 16 + (lane & 15), k = lane >> 4) per frame tile
     auto b_row = [&](int ft) {
         const int fl = ft * 16 + (lane & 15), fw = fl / kFramesPerWave;
@@ -333,7 +367,36 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
 
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
+    while (item < n_items) {
+      const int run = __builtin_amdgcn_readfirstlane(item / batch), clip = item - run * batch;
+      // (lengths / offsets are workgroup-uniform: move them to scalar registers once they have arrived)
+      const int n_valid = clamp_len(__builtin_amdgcn_readfirstlane(len_cur));
+      const int64_t off_x = ((int64_t)__builtin_amdgcn_readfirstlane((int)(off_cur >> 32)) << 32) |
+                            (uint32_t)__builtin_amdgcn_readfirstlane((int)off_cur);
+      const float* __restrict__ x = pcm + off_x;
+      if (tid == 0 && next_item < n_items) my_ticket = atomicAdd(ticket, 1u);     // -> the item after the next
+      if (next_item < n_items) {                   // lands while this item is processed
+          len_next = lengths[next_item % batch];
+          off_next = offsets[next_item % batch];
+      }
+      const int tile_begin = run * tiles_per_block;
+      const int tile_end = min(min(tile_begin + tiles_per_block, n_tiles), first_pad_tile_of(n_valid));
+      if (tile_begin < tile_end) {
+      float* __restrict__ out_clip = out + (size_t)clip * n_mels * n_frames;
+      // SpecAugment: mel-axis masks as two 64-bit words for the clip; time-axis masks per tile
+      // The clip's mask table goes to LDS once per item (read per tile from global memory it cost one HBM round
+      // trip per tile); it is first read after the "panel complete" barrier of the item's first tile.
+      const int nm = mask_tbl ? n_masks : 0;
+      int32_t* clip_masks = reinterpret_cast<int32_t*>(smem + kMaskOff);
+      if (tid < 3 * nm) clip_masks[tid] = mask_tbl[(size_t)clip * n_masks * 3 + tid];
+      uint64_t melmask_lo = 0, melmask_hi = 0;
+      if (!raw_ready) {
+          load_pass(x, n_valid, tile_begin * kTileFrames, 0, raw0);
+          load_pass(x, n_valid, tile_begin * kTileFrames, 1, raw1);
+      }
+      raw_ready = false;
+      float run_max = 0.0f;                         // mel energies (>= 1e-10 once any cell was produced)
+      for (int tile = tile_begin; tile < tile_end; ++tile) {
         const int t0 = tile * kTileFrames;
         {
             f2 ya[20], yb[20], pw0[11], pw1[11], q0[10], q1[10];
@@ -358,10 +421,25 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
             store_rows(0, pw0);
             store_rows(1, pw1);
         }
-        // next tile's PCM: issued now (few live registers from here on), lands during the mel projection
+        // next tile's PCM -- of this item, or the first tile of the workgroup's next item: issued now (few live
+        // registers from here on), lands during the mel projection
         if (tile + 1 < tile_end) {
-            load_pass(t0 + kTileFrames, 0, raw0);
-            load_pass(t0 + kTileFrames, 1, raw1);
+            load_pass(x, n_valid, t0 + kTileFrames, 0, raw0);
+            load_pass(x, n_valid, t0 + kTileFrames, 1, raw1);
+        } else if (next_item < n_items) {
+            // (the empty asm makes these values opaque here: otherwise the compiler computes the 56 load indices and
+            // bounds predicates of the next item at the top of this item and spills them across the whole tile loop)
+            int nv = clamp_len(__builtin_amdgcn_readfirstlane(len_next)), tb = __builtin_amdgcn_readfirstlane((next_item / batch) * tiles_per_block);
+            asm volatile("" : "+v"(nv), "+v"(tb));
+            nv = __builtin_amdgcn_readfirstlane(nv);
+            tb = __builtin_amdgcn_readfirstlane(tb);
+            const int64_t off_n = ((int64_t)__builtin_amdgcn_readfirstlane((int)(off_next >> 32)) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)off_next);
+            if (tb < min(n_tiles, first_pad_tile_of(nv))) {
+                load_pass(pcm + off_n, nv, tb * kTileFrames, 0, raw0);
+                load_pass(pcm + off_n, nv, tb * kTileFrames, 1, raw1);
+                raw_ready = true;
+            }
         }
         STAMP(5);
         __syncthreads();                                           // panel complete
@@ -369,6 +447,10 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 
         // ---------------- banded mel projection on the matrix cores + log epilogue --------------
         const uint64_t tmask = mask_bits(clip_masks, nm, STTFE_AXIS_TIME, t0, kTileFrames);
+        if (tile == tile_begin) {
+            melmask_lo = mask_bits(clip_masks, nm, STTFE_AXIS_FREQ, 0, 64);
+            melmask_hi = mask_bits(clip_masks, nm, STTFE_AXIS_FREQ, 64, 64);
+        }
         // Operands come as one b128 per lane and group of four k-steps: step i of group g multiplies bins
         // kstart + 16 g + 4 (lane >> 4) + i (tables.cpp lays the mel weights out to match).  Two interleaved
         // accumulation chains hide the 40-cycle dependent latency of the 16x16x4 MFMA; the next group's
@@ -455,20 +537,30 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         STAMP(7);
         __syncthreads();      // panel reads done before the next tile's slab writes
         STAMP(8);
+      }   // tiles of the item
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) run_max = fmaxf(run_max, __shfl_xor(run_max, off, 64));
+      if (lane == 0 && run_max > 0.0f)
+          atomicMax(&keys[(size_t)clip * kKeysPerClip], float_to_key(__log2f(run_max) * 0.30102999566398120f));
+      }   // item has tiles
+      // publish the ticket taken at the top of this item (two alternating LDS slots: a slot is rewritten only after
+      // the barrier of the following item, which every thread reaches after this read)
+      unsigned* slot = reinterpret_cast<unsigned*>(smem + kTicketOff) + 1 + (iter & 1u);
+      if (tid == 0) *slot = (next_item < n_items) ? my_ticket + gridDim.x : (unsigned)n_items;
+      __syncthreads();
+      const int after_next = (int)min(*slot, (unsigned)n_items);
+      ++iter;
+      item = next_item;
+      next_item = after_next;
+      len_cur = len_next;
+      off_cur = off_next;
     }
 #ifdef STTFE_STAMPS
     if (g_stamp_buf && lane == 0) {
-        unsigned long long* dst = g_stamp_buf + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kWaves + wave) * 10;
+        unsigned long long* dst = g_stamp_buf + ((size_t)blockIdx.x * kWaves + wave) * 10;
         for (int i = 0; i < 10; ++i) dst[i] = stamp_sum[i];
     }
 #endif
-
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        run_max = fmaxf(run_max, __shfl_xor(run_max, off, 64));
-    }
-    if (lane == 0 && run_max > 0.0f)
-        atomicMax(&keys[(size_t)clip * kKeysPerClip], float_to_key(__log2f(run_max) * 0.30102999566398120f));
 }
 
 // Clamp / fill pass.  grid.x = row split, grid.y = clips: workgroup x owns mel rows x, x + gridDim.x, ... of its clip.
@@ -611,7 +703,7 @@ extern "C" int sttfe_debug_set_stamp_buffer(void* dev_buf) {
 
 extern "C" int sttfe_whisper_workspace_bytes(int batch, size_t* bytes) {
     if (batch < 0 || !bytes) return STTFE_E_INVALID_ARG;
-    *bytes = (size_t)batch * wh::kKeysPerClip * sizeof(unsigned);
+    *bytes = (size_t)batch * wh::kKeysPerClip * sizeof(unsigned) + 64;      // keys + the work-item ticket counter
     return STTFE_OK;
 }
 
@@ -649,17 +741,19 @@ extern "C" int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, co
         return v < 0 || v > wh::kMaxTiles ? 0 : v;
     }();
     int tiles_per_block = g_whisper_tiles_per_block ? g_whisper_tiles_per_block : tpb_env;
-    if (tiles_per_block == 0) {
-        // two 4-wave workgroups per CU, 256 CUs: aim for >= 2 rounds of workgroups, runs as long as possible
-        const int choices[5] = {21, 9, 7, 5, 3};
-        tiles_per_block = 3;
-        for (int c : choices)
-            if ((long)batch * ((n_tiles + c - 1) / c) >= 1024) {
-                tiles_per_block = c;
-                break;
-            }
-    }
-    const int blocks_x = (n_tiles + tiles_per_block - 1) / tiles_per_block;
+    // Kernel 1 runs as persistent workgroups (two per CU) that walk (tile run, clip) items; short runs keep the
+    // workgroups balanced when clip lengths differ, and the tables are staged once per workgroup, not per run.
+    // tiles_per_block == 0: the kernel picks the run length itself from the clip lengths it finds on the device
+    if ((long)n_tiles * batch > 0x3fffffffL) return STTFE_E_UNSUPPORTED;
+    static const int resident = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            cus = 256;
+        return 2 * cus;
+    }();
+    const long most_items = (long)batch * ((n_tiles + 2) / 3);      // fewer workgroups than that cannot all find work
+    const int grid = most_items < resident ? (int)most_items : resident;
     const auto* tab = reinterpret_cast<const WhisperTablesHeader*>(dev_tables);
     {
         ScopedTiming t(kTimeWhisperStftMel, stream);
@@ -669,8 +763,9 @@ extern "C" int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, co
 #else
         const int dyn_lds = 0;
 #endif
-        hipLaunchKernelGGL(whisper_stft_mel_kernel, dim3(blocks_x, batch), dim3(wh::kThreads), dyn_lds, stream,
-                           pcm, offsets, lengths, n_mels, n_frames, tab, out, keys, mask_tbl, n_masks, tiles_per_block);
+        hipLaunchKernelGGL(whisper_stft_mel_kernel, dim3(grid), dim3(wh::kThreads), dyn_lds, stream,
+                           pcm, offsets, lengths, n_mels, n_frames, tab, out, keys, mask_tbl, n_masks, tiles_per_block,
+                           batch, keys + (size_t)batch * wh::kKeysPerClip);
     }
     {
         ScopedTiming t(kTimeWhisperClamp, stream);
