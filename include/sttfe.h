@@ -58,7 +58,8 @@ int sttfe_whisper_tables_build(int n_mels, void* host_blob, size_t bytes);
 /* The dense (n_mels x 201) float32 mel bank the tables were derived from (for inspection/tests). */
 int sttfe_whisper_mel_bank(int n_mels, float* host_dense);
 
-/* Bytes of device workspace needed for a batch (per-clip max key + per-tile min keys). */
+/* Bytes of device workspace needed for a batch (per-clip max key + per-tile min keys + one work-item ticket
+ * counter; the entry point zeroes it itself, contents need not survive between calls). */
 int sttfe_whisper_workspace_bytes(int batch, size_t* bytes);
 
 /*
@@ -155,8 +156,9 @@ int sttfe_normalize_trim(float* pcm, int64_t* offsets, int32_t* lengths, int bat
                          int normalize, int trim, float silence_threshold,
                          void* workspace, size_t workspace_bytes, void* stream);
 
-/* Consecutive 48-frame tiles one workgroup of the STFT kernel walks (0 = automatic, the default: 21 for batches that fill the chip, down to 3 for small ones).
- * Tuning knob, no counterpart in the reference. */
+/* Consecutive 48-frame tiles per work item of the STFT kernel (0 = automatic, the default: the kernel derives it
+ * from the clip lengths it finds on the device -- a third of the clip for uniform batches, a fifth of the
+ * longest clip otherwise, within [3, 21]).  Tuning knob, no counterpart in the reference. */
 int sttfe_set_whisper_tiles_per_block(int tiles);
 
 /* ------------------------------------------------------------- measurement support -----------
