@@ -156,6 +156,26 @@ int sttfe_normalize_trim(float* pcm, int64_t* offsets, int32_t* lengths, int bat
                          int normalize, int trim, float silence_threshold,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------- waveform augmentations --------
+ * Replaces: AudioAugmentationCPU.apply_time_domain_augmentations (reference src/data.py:152-183, called per clip at
+ * src/data.py:328-329): Gaussian noise (:155-157), torchaudio Vol "amplitude" gain with its clamp to [-1, 1]
+ * (:170-174) and torchaudio Fade, linear, same length in and out (:177-181), applied in place to packed PCM in the
+ * reference's order.  Speed perturbation (:160-161) is a rational resample: sttfe_resample_peak with a
+ * (round(factor * rate) : rate) plan; pitch shift (:164-167) is not provided.
+ *   params  : device int32 [batch][4] = {STTFE_AUG_* flags of the clip, float bits of noise_factor,
+ *             float bits of the amplitude gain, fade samples}; the host draws the gates and values in the
+ *             reference's RNG order (speech_to_text_amd/augment.py).
+ *   noise   : device float32 standard-normal samples, clip b at noise[noise_offsets[b] ...] (lengths[b] of them),
+ *             or NULL (then no noise is added); torch.randn drawn on the host reproduces the reference bit for bit.
+ *   stages  : which flagged stages this call applies (noise before a speed resample, gain and fade after it).
+ *   max_length : longest clip of the batch (grid sizing). */
+#define STTFE_AUG_NOISE 1
+#define STTFE_AUG_GAIN 2
+#define STTFE_AUG_FADE 4
+int sttfe_waveform_augment(float* pcm, const int64_t* offsets, const int32_t* lengths, int batch, int64_t max_length,
+                           const int32_t* params, const float* noise, const int64_t* noise_offsets, int stages,
+                           void* stream);
+
 /* Consecutive 48-frame tiles per work item of the STFT kernel (0 = automatic, the default: the kernel derives it
  * from the clip lengths it finds on the device -- a third of the clip for uniform batches, a fifth of the
  * longest clip otherwise, within [3, 21]).  Tuning knob, no counterpart in the reference. */

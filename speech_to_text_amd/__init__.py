@@ -6,7 +6,7 @@ kernels behind the C-ABI library ``libsttfe.so`` (``include/sttfe.h``); there is
 """
 __version__ = "0.1.0"
 
-from .augment import SpecAugmentSampler  # noqa: F401
+from .augment import GpuWaveformAugmenter, SpecAugmentSampler, WaveformAugmentSampler, WaveformDraw  # noqa: F401
 from .config import AugmentationConfig, DataConfig  # noqa: F401
 from .data import AudioCollator, GpuFrontEnd  # noqa: F401
 from .preprocess import GpuAudioPreprocessor, PackedAudio, ResamplePlan  # noqa: F401

@@ -49,6 +49,7 @@ def _declare(lib):
         "sttfe_preprocess_workspace_bytes": [c_int, POINTER(c_size_t)],
         "sttfe_resample_peak": [p, p, p, c_int, c_int, c_int64, p, p, p, p, p, p, c_size_t, p],
         "sttfe_normalize_trim": [p, p, p, c_int, c_int64, c_int, c_int, c_float, p, c_size_t, p],
+        "sttfe_waveform_augment": [p, p, p, c_int, c_int64, p, p, p, c_int, p],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name, None)

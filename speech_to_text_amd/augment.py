@@ -19,10 +19,18 @@ Draw order per clip (torchaudio 2.5.1 ``functional.mask_along_axis`` with p = 1.
 """
 from __future__ import annotations
 
+import ctypes
+import logging
 import random
-from typing import Any, List, Sequence, Tuple
+import struct
+from dataclasses import dataclass
+from math import gcd
+from typing import Any, Dict, List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
+
+logger = logging.getLogger(__name__)
 
 AXIS_FREQ = 0        # STTFE_AXIS_FREQ
 AXIS_TIME = 1        # STTFE_AXIS_TIME
@@ -72,3 +80,217 @@ class SpecAugmentSampler:
             for i, (axis, s, e) in enumerate(self.draw_clip(int(n_freq), int(n_time))):
                 tbl[b, i, 0], tbl[b, i, 1], tbl[b, i, 2] = axis, s, e
         return tbl
+
+
+# ------------------------------------------------------------------ waveform-domain augmentations
+AUG_NOISE, AUG_GAIN, AUG_FADE = 1, 2, 4          # STTFE_AUG_*
+
+
+@dataclass
+class WaveformDraw:
+    """The random draws of one clip (reference ``src/data.py:155-181``); None = the gate did not pass."""
+    noise_factor: Optional[float] = None
+    noise: Optional[torch.Tensor] = None         # (n,) host standard-normal samples when noise_source == "host"
+    speed_factor: Optional[float] = None
+    pitch_steps: Optional[int] = None            # drawn (keeps the RNG streams aligned) but not applied
+    gain: Optional[float] = None
+    fade_samples: Optional[int] = None
+
+
+class WaveformAugmentSampler:
+    """Draws the time-domain augmentation parameters in the reference's RNG order.
+
+    Counterpart of ``AudioAugmentationCPU.apply_time_domain_augmentations`` (``src/data.py:152-183``):
+    per clip, in order, ``random.random()`` gates for noise / speed / pitch / volume / fade, each followed
+    (when it passes) by its value draw: ``torch.randn_like(audio)``, ``torch.randint(len(factors), ())``,
+    ``random.randint(*pitch_shift_range)``, ``random.uniform(*volume_range_db)``, none for fade.
+
+    ``noise_source="host"`` draws the noise itself from the torch CPU generator, exactly like the reference
+    (bit parity; n floats per noisy clip cross PCIe); ``"device"`` leaves it to the GPU generator (same
+    distribution, different stream) -- the default, since the noise is 4 bytes per sample.
+    Pitch shift is not built: its draws are consumed and a warning is logged once.
+    """
+
+    def __init__(self, config: Any = None, sample_rate: int = 16000, noise_source: str = "device", **overrides):
+        get = lambda k, d: overrides.get(k, getattr(config, k, d) if config is not None else d)
+        if noise_source not in ("host", "device"):
+            raise ValueError("noise_source must be 'host' or 'device'")
+        self.noise_source = noise_source
+        self.sample_rate = int(sample_rate)
+        self.add_noise = bool(get("add_noise", True))
+        self.noise_probability = float(get("noise_probability", 0.3))
+        self.noise_factor = float(get("noise_factor", 0.02))
+        self.speed_perturbation = bool(get("speed_perturbation", True))
+        self.speed_probability = float(get("speed_probability", 0.3))
+        lo, hi = get("speed_factor_range", (0.9, 1.1))
+        self.speed_factors = np.linspace(lo, hi, int(get("speed_num_steps", 3))).tolist()   # src/data.py:145-149
+        self.pitch_shift = bool(get("pitch_shift", True))
+        self.pitch_probability = float(get("pitch_probability", 0.3))
+        self.pitch_shift_range = tuple(get("pitch_shift_range", (-2, 2)))
+        self.volume_perturbation = bool(get("volume_perturbation", True))
+        self.volume_probability = float(get("volume_probability", 0.3))
+        self.volume_range_db = tuple(get("volume_range_db", (-10, 10)))
+        self.fade_inout = bool(get("fade_inout", True))
+        self.fade_probability = float(get("fade_probability", 0.2))
+        self.fade_duration = float(get("fade_duration", 0.1))
+        self._warned_pitch = False
+
+    def draw_clip(self, n_samples: int) -> WaveformDraw:
+        d = WaveformDraw()
+        if self.add_noise and random.random() < self.noise_probability:
+            d.noise_factor = self.noise_factor
+            if self.noise_source == "host":
+                d.noise = torch.randn(1, int(n_samples)).reshape(-1)       # == randn_like of the (1, n) clip
+        if self.speed_perturbation and random.random() < self.speed_probability:
+            d.speed_factor = float(self.speed_factors[int(torch.randint(len(self.speed_factors), ()))])
+        if self.pitch_shift and random.random() < self.pitch_probability:
+            d.pitch_steps = random.randint(*self.pitch_shift_range)
+            if not self._warned_pitch:
+                logger.warning("pitch shift is not available in the GPU front-end: draw consumed, clip left unshifted")
+                self._warned_pitch = True
+        if self.volume_perturbation and random.random() < self.volume_probability:
+            d.gain = 10 ** (random.uniform(*self.volume_range_db) / 20.0)
+        if self.fade_inout and random.random() < self.fade_probability:
+            d.fade_samples = int(self.fade_duration * self.sample_rate)
+        return d
+
+    def speed_rates(self, factor: float) -> Tuple[int, int]:
+        """(source, target) of torchaudio.functional.speed's resample, reduced by their gcd."""
+        source, target = int(factor * self.sample_rate), self.sample_rate
+        g = gcd(source, target)
+        return source // g, target // g
+
+    def out_length(self, n: int, d: WaveformDraw) -> int:
+        """Clip length after the draw's speed perturbation (ceil(target * n / source))."""
+        if d.speed_factor is None or d.speed_factor == 1.0:
+            return int(n)
+        src, dst = self.speed_rates(d.speed_factor)
+        return int(n) if src == dst else (dst * int(n) + src - 1) // src
+
+
+def _fbits(v: float) -> int:
+    return struct.unpack("<i", struct.pack("<f", float(v)))[0]
+
+
+class GpuWaveformAugmenter:
+    """Applies a batch of ``WaveformDraw`` to packed PCM on the GPU (``sttfe_waveform_augment`` + resampler).
+
+    Order as in the reference: noise -> speed -> (pitch: skipped) -> volume -> fade.
+    """
+
+    def __init__(self, sampler: WaveformAugmentSampler):
+        self.sampler = sampler
+        self._plans: Dict[Tuple[int, int], Any] = {}
+
+    def _plan(self, src: int, dst: int):
+        from .preprocess import ResamplePlan
+        p = self._plans.get((src, dst))
+        if p is None:
+            p = ResamplePlan(src, dst)
+            self._plans[(src, dst)] = p
+        return p
+
+    def apply(self, packed, draws: Sequence[WaveformDraw]):
+        """``packed``: preprocess.PackedAudio (mono, device).  Returns a PackedAudio (new buffers when any clip's
+        speed changed; otherwise the same buffers, modified in place).  Clips whose fade is longer than the clip
+        are dropped (``keep`` False): torchaudio's Fade raises there and the reference skips the sample."""
+        from . import _lib
+        from .preprocess import _ALIGN, PackedAudio
+        L = _lib.lib()
+        device = packed.pcm.device
+        B = len(draws)
+        if B == 0:
+            return packed
+        lens = list(packed.host_lengths)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        params = torch.zeros((B, 4), dtype=torch.int32)
+        keep = list(packed.keep)
+        noise_dev = noise_off = None
+        any_noise = any(d.noise_factor is not None for d in draws)
+        if any_noise:
+            starts, total = [], 0
+            for b, d in enumerate(draws):
+                starts.append(total)
+                if d.noise_factor is not None:
+                    total += (lens[b] + _ALIGN - 1) // _ALIGN * _ALIGN
+            if self.sampler.noise_source == "host":
+                stage = torch.zeros(total + _ALIGN, dtype=torch.float32, pin_memory=torch.cuda.is_available())
+                for b, d in enumerate(draws):
+                    if d.noise_factor is not None:
+                        stage[starts[b]:starts[b] + lens[b]] = d.noise[:lens[b]]
+                noise_dev = stage.to(device, non_blocking=True)
+            else:
+                noise_dev = torch.randn(total + _ALIGN, dtype=torch.float32, device=device)
+            noise_off = torch.tensor(starts, dtype=torch.int64).to(device, non_blocking=True)
+        for b, d in enumerate(draws):
+            flags = 0
+            if d.noise_factor is not None:
+                flags |= AUG_NOISE
+                params[b, 1] = _fbits(d.noise_factor)
+            if d.gain is not None:
+                flags |= AUG_GAIN
+                params[b, 2] = _fbits(d.gain)
+            if d.fade_samples is not None:
+                flags |= AUG_FADE
+                params[b, 3] = int(d.fade_samples)
+            params[b, 0] = flags
+        params_dev = params.to(device, non_blocking=True)
+        speed_groups: Dict[Tuple[int, int], List[int]] = {}
+        for b, d in enumerate(draws):
+            if d.speed_factor is not None and d.speed_factor != 1.0:
+                src, dst = self.sampler.speed_rates(d.speed_factor)
+                if src != dst:
+                    speed_groups.setdefault((src, dst), []).append(b)
+
+        def run(p, stages):
+            with torch.cuda.device(device):
+                _lib.check(L.sttfe_waveform_augment(_lib.ptr(p.pcm), _lib.ptr(p.offsets), _lib.ptr(p.lengths), B,
+                                                    int(max(p.host_lengths) if B else 0), _lib.ptr(params_dev),
+                                                    _lib.ptr(noise_dev) if noise_dev is not None else None,
+                                                    _lib.ptr(noise_off) if noise_off is not None else None,
+                                                    int(stages), stream), "sttfe_waveform_augment")
+
+        if not speed_groups:
+            run(packed, AUG_NOISE | AUG_GAIN | AUG_FADE)
+            out = packed
+        else:
+            if any_noise:
+                run(packed, AUG_NOISE)
+            # speed: every group through the resampler into a fresh packing; untouched clips are copied
+            new_lens = [self.sampler.out_length(lens[b], draws[b]) for b in range(B)]
+            starts, total = [], 0
+            for n in new_lens:
+                starts.append(total)
+                total += (n + _ALIGN - 1) // _ALIGN * _ALIGN
+            pcm_out = torch.empty(total + _ALIGN, dtype=torch.float32, device=device)
+            out_offsets = torch.tensor(starts, dtype=torch.int64).to(device, non_blocking=True)
+            out_lengths = torch.empty(B, dtype=torch.int32, device=device)
+            ws_bytes = ctypes.c_size_t()
+            moved = set()
+            groups = dict(speed_groups)
+            rest = [b for b in range(B) if not any(b in g for g in speed_groups.values())]
+            if rest:
+                groups[(1, 1)] = rest
+            for (src, dst), idx in groups.items():
+                sel = torch.tensor(idx, dtype=torch.int64).to(device, non_blocking=True)
+                in_off, in_len = packed.offsets[sel].contiguous(), packed.lengths[sel].contiguous()
+                o_off, o_len = out_offsets[sel].contiguous(), torch.empty(len(idx), dtype=torch.int32, device=device)
+                _lib.check(L.sttfe_preprocess_workspace_bytes(len(idx), ctypes.byref(ws_bytes)))
+                ws = torch.empty(max(ws_bytes.value, 1), dtype=torch.uint8, device=device)
+                plan = self._plan(src, dst) if (src, dst) != (1, 1) else None
+                with torch.cuda.device(device):
+                    _lib.check(L.sttfe_resample_peak(_lib.ptr(packed.pcm), _lib.ptr(in_off), _lib.ptr(in_len), len(idx),
+                                                     1, int(max(lens[b] for b in idx)),
+                                                     _lib.ptr(plan.on(device)) if plan else None,
+                                                     _lib.ptr(plan.host) if plan else None,
+                                                     _lib.ptr(pcm_out), _lib.ptr(o_off), _lib.ptr(o_len),
+                                                     _lib.ptr(ws), ws.numel(), stream), "sttfe_resample_peak")
+                out_lengths[sel] = o_len
+                moved.update(idx)
+            durations_rate = packed.sample_rate
+            out = PackedAudio(pcm_out, out_offsets, out_lengths, new_lens, durations_rate, keep)
+            run(out, AUG_GAIN | AUG_FADE)
+        for b, d in enumerate(draws):
+            if d.fade_samples is not None and d.fade_samples > out.host_lengths[b]:
+                out.keep[b] = False
+        return out

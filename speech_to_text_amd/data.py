@@ -30,7 +30,7 @@ import numpy as np
 import torch
 from torch.nn.utils.rnn import pad_sequence
 
-from .augment import SpecAugmentSampler
+from .augment import GpuWaveformAugmenter, SpecAugmentSampler, WaveformAugmentSampler
 from .processors import (BatchFeature, HipSpeech2TextFeatureExtractor, HipWhisperFeatureExtractor,
                          _resolve_device)
 
@@ -102,7 +102,8 @@ class GpuFrontEnd:
     def __init__(self, config: Any, model_type: str = "whisper", transpose_features: bool = False,
                  tokenizer: Any = None, split: str = "train", feature_size: Optional[int] = None,
                  device: Optional[Union[str, torch.device]] = None,
-                 max_source_positions: Optional[int] = None, max_target_positions: Optional[int] = None):
+                 max_source_positions: Optional[int] = None, max_target_positions: Optional[int] = None,
+                 noise_source: str = "device"):
         self.config = config
         self.model_type = model_type.lower()
         if self.model_type not in ("whisper", "speech2text"):
@@ -114,7 +115,11 @@ class GpuFrontEnd:
         self._device_arg = device
         aug = getattr(config, "augmentation", None)
         # src/data.py:222: augmentation object only when augmentation.enabled; :360 train split only
-        self.sampler = SpecAugmentSampler(aug) if (aug is not None and getattr(aug, "enabled", False)) else None
+        enabled = aug is not None and getattr(aug, "enabled", False)
+        self.sampler = SpecAugmentSampler(aug) if enabled else None
+        # src/data.py:328-329: waveform-domain augmentations sit between the preprocessor and the extractor
+        self.wave_sampler = WaveformAugmentSampler(aug, self.sample_rate, noise_source) if enabled else None
+        self.wave_augmenter = GpuWaveformAugmenter(self.wave_sampler) if enabled else None
         if self.model_type == "whisper":
             self.feature_extractor = HipWhisperFeatureExtractor(feature_size or 80, device=device)
         else:
@@ -141,14 +146,26 @@ class GpuFrontEnd:
         return pad_sequence(ids, batch_first=True, padding_value=-100)
 
     # ---------------------------------------------------------------- features
+    def _spec_shape(self, n_samples: int):
+        """(n_freq, n_time) of one clip's features, as the reference's per-clip extractor call returns them."""
+        fe = self.feature_extractor
+        if self.model_type == "whisper":
+            return fe.feature_size, fe.nb_max_frames
+        return fe.num_mel_bins, fe.num_frames(int(n_samples), int(self.max_source_positions or 0) or None)
+
     def features(self, pcm: torch.Tensor, offsets: torch.Tensor, lengths: torch.Tensor,
-                 host_lengths: Sequence[int]) -> Dict[str, torch.Tensor]:
-        """Packed 16 kHz PCM on the device -> {"input_features"[, "attention_mask"]} (device tensors)."""
+                 host_lengths: Sequence[int], mask_table: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """Packed 16 kHz PCM on the device -> {"input_features"[, "attention_mask"]} (device tensors).
+
+        ``mask_table``: SpecAugment masks already drawn by the caller (``__call__`` draws them clip by clip,
+        interleaved with the waveform draws, as the reference does); None = draw them here."""
         fe = self.feature_extractor
         augment = self.sampler is not None and self.split == "train"
         B = len(host_lengths)
         if self.model_type == "whisper":
-            table = self.sampler.mask_table([(fe.feature_size, fe.nb_max_frames)] * B) if augment else None
+            table = mask_table
+            if table is None and augment:
+                table = self.sampler.mask_table([(fe.feature_size, fe.nb_max_frames)] * B)
             feats = fe.extract(pcm, offsets, lengths, mask_table=table)               # (B, M, 3000)
             if self.transpose_features:
                 feats = feats.transpose(1, 2)
@@ -156,7 +173,9 @@ class GpuFrontEnd:
         max_frames = int(self.max_source_positions or 0)
         frames = [fe.num_frames(int(n), max_frames or None) for n in host_lengths]
         t_max = max(frames) if frames else 0
-        table = self.sampler.mask_table([(fe.num_mel_bins, t) for t in frames]) if augment else None
+        table = mask_table
+        if table is None and augment:
+            table = self.sampler.mask_table([(fe.num_mel_bins, t) for t in frames])
         feats, attn = fe.extract(pcm, offsets, lengths, t_max, max_frames, mask_table=table,
                                  attention_dtype=torch.int64)                         # (B, T_max, M)
         if not self.transpose_features:
@@ -177,7 +196,28 @@ class GpuFrontEnd:
         lengths = torch.tensor(host_lengths, dtype=torch.int32).to(device, non_blocking=True)
         offsets = (torch.arange(B, dtype=torch.int64) * n_max).to(device, non_blocking=True)
         texts = list(batch.get("texts", batch.get("text", [""] * B)))
-        result: Dict[str, Any] = self.features(pcm.reshape(-1), offsets, lengths, host_lengths)
+        pcm = pcm.reshape(-1)
+        table = None
+        if self.wave_sampler is not None and self.split == "train":
+            # One clip after the other, as CommonVoiceDataset.__getitem__ does (src/data.py:328-329, :360-361):
+            # the waveform draws of clip b, then its SpecAugment draws, from the same two generators.
+            from .preprocess import PackedAudio
+            draws, rows = [], []
+            for n in host_lengths:
+                d = self.wave_sampler.draw_clip(n)
+                draws.append(d)
+                rows.append(self.sampler.draw_clip(*self._spec_shape(self.wave_sampler.out_length(n, d))))
+            packed = self.wave_augmenter.apply(
+                PackedAudio(pcm, offsets, lengths, list(host_lengths), self.sample_rate, [True] * B), draws)
+            if not all(packed.keep):
+                # torchaudio's Fade raises when the fade is longer than the clip, and the reference lets it propagate
+                raise RuntimeError("fade longer than the clip (fade_duration vs min_duration)")
+            pcm, offsets, lengths, host_lengths = packed.pcm, packed.offsets, packed.lengths, packed.host_lengths
+            table = torch.zeros((B, max(self.sampler.masks_per_clip, 1), 3), dtype=torch.int32)
+            for b, masks in enumerate(rows):
+                for i, (axis, s0, e0) in enumerate(masks):
+                    table[b, i, 0], table[b, i, 1], table[b, i, 2] = axis, s0, e0
+        result: Dict[str, Any] = self.features(pcm, offsets, lengths, host_lengths, mask_table=table)
         labels = self._labels(texts)
         if labels is not None:
             result["labels"] = labels.to(device, non_blocking=True)

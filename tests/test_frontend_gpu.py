@@ -30,7 +30,10 @@ def raw_batch(seed, lengths):
     clips = synth_batch(seed, lengths)
     samples = [{"audio": torch.from_numpy(c)[None, :], "text": "txt" * (i + 1)} for i, c in enumerate(clips)]
     samples.insert(1, None)                                           # a failed clip (src/data.py:307-321)
-    cfg = DataConfig(processing_and_augmentation_device="cuda", augmentation=AugmentationConfig(enabled=True))
+    # SpecAugment only, unless a test switches the waveform-domain stages back on
+    aug = AugmentationConfig(enabled=True, add_noise=False, speed_perturbation=False, pitch_shift=False,
+                             volume_perturbation=False, fade_inout=False)
+    cfg = DataConfig(processing_and_augmentation_device="cuda", augmentation=aug)
     return clips, cfg, AudioCollator(cfg, "whisper")(samples)
 
 
@@ -100,3 +103,29 @@ def test_reference_batch_without_lengths_and_empty():
     front = GpuFrontEnd(cfg, "whisper", split="test", device=DEV)
     out = front(raw)
     assert out["input_features"].shape == (2, 80, 3000) and front(None) is None
+
+
+def test_whisper_train_batch_with_waveform_and_spec_augmentation():
+    """The whole train-split chain of CommonVoiceDataset.__getitem__ (src/data.py:326-361) for a batch: per clip
+    the waveform draws + augmentations, the extractor, then the SpecAugment draws -- same generators, same order."""
+    from oracle import waveform_aug as W
+    from oracle.whisper import whisper_features
+    clips, cfg, raw = raw_batch(34, [48000, 80000, 16000, 123457, 30000, 64000])
+    a = cfg.augmentation
+    a.add_noise = a.speed_perturbation = a.pitch_shift = a.volume_perturbation = a.fade_inout = True
+    a.noise_probability = a.speed_probability = a.volume_probability = a.fade_probability = 0.6
+    front = GpuFrontEnd(cfg, "whisper", False, split="train", device=DEV, noise_source="host")
+    torch.manual_seed(7)
+    random.seed(7)
+    out = front(raw)
+    torch.manual_seed(7)
+    random.seed(7)
+    got = out["input_features"].cpu().numpy()
+    kinds = set()
+    for b, c in enumerate(clips):
+        d = W.draw_time_domain(a, c.shape[0])
+        masks = S.draw_clip_masks(80, 3000)
+        kinds |= {k for k in ("noise_factor", "speed_factor", "gain", "fade_samples") if getattr(d, k) is not None}
+        e = S.apply_masks(whisper_features([W.apply_time_domain(c, d)], 80)[0], masks)
+        assert np.abs(got[b] - e).max() <= 1e-4, (b, d.speed_factor, d.gain, d.fade_samples)
+    assert len(kinds) == 4                                            # the seed exercises every built stage
