@@ -13,6 +13,7 @@ max-over-ranks time.
   whisper80         configs[0] shape at GPU batch: 1024 x 30 s clips @16 kHz -> (1024, 80, 3000)   [headline]
   s2t               configs[1]: Speech2Text fbank + CMVN, 256 ragged 2-10 s clips, dynamic padding
   resample_whisper  configs[2]: 48 kHz Common-Voice-length clips -> resample + normalise -> Whisper-80, batch 512
+  resample_whisper_s16  the same with int16 decoded PCM (sttfe_resample_peak_s16; SURVEY 8d: reported as its own line)
   whisper128_aug    configs[3]: Whisper 128-mel + SpecAugment masks, Common-Voice-length clips, batch 1024
   corpus            configs[4]: offline precompute of a 30 000-clip (~43 h) Common-Voice-length corpus, clip i on rank
                     i mod G, chunks of 1024 clips, Whisper-80 features (strong scaling: the corpus is fixed)
@@ -101,7 +102,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="whisper80",
-                    choices=["whisper80", "s2t", "resample_whisper", "whisper128_aug", "corpus"])
+                    choices=["whisper80", "s2t", "resample_whisper", "resample_whisper_s16", "whisper128_aug", "corpus"])
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (0 = the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -131,6 +132,9 @@ def main():
 
     L = _lib.lib()
     wl = args.workload
+    s16 = wl == "resample_whisper_s16"
+    if s16:
+        wl = "resample_whisper"
     seed = {"whisper80": 101, "s2t": 102, "resample_whisper": 103, "whisper128_aug": 104, "corpus": 105}[wl] * 1000 + rank
     rng = np.random.default_rng(seed)
     B = args.batch or {"whisper80": 1024, "s2t": 256, "resample_whisper": 512, "whisper128_aug": 1024, "corpus": 1024}[wl]
@@ -161,6 +165,8 @@ def main():
     n_max = (int(lens.max()) + 63) // 64 * 64
     pcm2d = synth_batch_device(seed, len(lens), n_max, device, sample_rate=sr)
     pcm = pcm2d.reshape(-1)
+    if s16:                                        # decoded PCM as the decoder delivers it
+        pcm = torch.clamp(torch.round(pcm * 32767.0), -32768, 32767).to(torch.int16)
     offsets = (torch.arange(len(lens), dtype=torch.int64) * n_max).to(device)
     lengths = torch.tensor(lens, dtype=torch.int32, device=device)
     host_lens = [int(v) for v in lens]
@@ -272,7 +278,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": shapes[wl], "clips_per_gpu": B, "n_mels": n_mels,
+            "config": {"workload": shapes[wl] + (" (int16 decoded PCM)" if s16 else ""), "clips_per_gpu": B, "n_mels": n_mels,
                        "sharding": f"clip-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

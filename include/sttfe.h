@@ -144,6 +144,16 @@ int sttfe_resample_peak(const float* pcm_in, const int64_t* in_offsets, const in
                         float* pcm_out, const int64_t* out_offsets, int32_t* out_lengths,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same call for int16 PCM as decoders deliver it (sample / 32768, the normalisation torchaudio.load applies at
+ * reference src/data.py:313; exact in float32): pcm_in holds int16 samples, offsets and lengths count samples.
+ * Half the bytes over PCIe and out of HBM, no conversion pass (decoded-PCM ingest).
+ * pcm_out may not alias pcm_in. */
+int sttfe_resample_peak_s16(const int16_t* pcm_in, const int64_t* in_offsets, const int32_t* in_lengths,
+                            int batch, int channels, int64_t max_in_length,
+                            const void* dev_plan, const void* host_plan,
+                            float* pcm_out, const int64_t* out_offsets, int32_t* out_lengths,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /*
  * In place on the output of sttfe_resample_peak (same workspace, same stream):
  *   normalize : pcm <- pcm / (peak + 1e-8) for clips with peak > 0 (IEEE float32 division);

@@ -48,6 +48,7 @@ def _declare(lib):
         "sttfe_resample_out_length": [c_int, c_int, c_int64, POINTER(c_int64)],
         "sttfe_preprocess_workspace_bytes": [c_int, POINTER(c_size_t)],
         "sttfe_resample_peak": [p, p, p, c_int, c_int, c_int64, p, p, p, p, p, p, c_size_t, p],
+        "sttfe_resample_peak_s16": [p, p, p, c_int, c_int, c_int64, p, p, p, p, p, p, c_size_t, p],
         "sttfe_normalize_trim": [p, p, p, c_int, c_int64, c_int, c_int, c_float, p, c_size_t, p],
         "sttfe_waveform_augment": [p, p, p, c_int, c_int64, p, p, p, c_int, p],
     }

@@ -47,16 +47,23 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // Sample i of the mono mix of a (channels, n) planar clip (src/data.py:66-67: torch.mean(dim=0)).
-__device__ __forceinline__ float mono_at(const float* __restrict__ x, int n, int channels, int i) {
-    if (channels == 1) return x[i];
+// Input samples are float32, or int16 as decoders deliver them: x / 32768 (what torchaudio.load's normalisation
+// does, reference src/data.py:313; exact in float32), so that the int16 path halves the bytes crossing PCIe and
+// HBM without a conversion pass.
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(int16_t v) { return (float)v * (1.0f / 32768.0f); }
+
+template <typename TIn>
+__device__ __forceinline__ float mono_at(const TIn* __restrict__ x, int n, int channels, int i) {
+    if (channels == 1) return to_f32(x[i]);
     float s = 0.f;
-    for (int c = 0; c < channels; ++c) s += x[(size_t)c * n + i];
+    for (int c = 0; c < channels; ++c) s += to_f32(x[(size_t)c * n + i]);
     return s / (float)channels;
 }
 
-template <int ORIG>
+template <int ORIG, typename TIn>
 __global__ __launch_bounds__(rs::kThreads) void decimate_peak_kernel(
-    const float* __restrict__ pcm_in, const int64_t* __restrict__ in_off, const int32_t* __restrict__ in_len,
+    const TIn* __restrict__ pcm_in, const int64_t* __restrict__ in_off, const int32_t* __restrict__ in_len,
     int channels, const ResamplePlanHeader* __restrict__ plan, float* __restrict__ pcm_out,
     const int64_t* __restrict__ out_off, int32_t* __restrict__ out_len, unsigned* __restrict__ peak_keys,
     int tiles_per_block) {
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(rs::kThreads) void decimate_peak_kernel(
     const int tile_begin = blockIdx.x * tiles_per_block;
     const int tile_end = min(tile_begin + tiles_per_block, n_tiles);
     if (tile_begin >= tile_end) return;
-    const float* __restrict__ x = pcm_in + in_off[clip];
+    const TIn* __restrict__ x = pcm_in + in_off[clip];
     float* __restrict__ y = pcm_out + out_off[clip];
     const float* __restrict__ h = reinterpret_cast<const float*>(plan + 1) + 2 * plan->new_rate;   // taps of phase 0
     const int width = plan->width;
@@ -83,20 +90,52 @@ __global__ __launch_bounds__(rs::kThreads) void decimate_peak_kernel(
         // padded[ORIG * o0 + g] = x[ORIG * o0 + g - width] (zero outside the clip) -> rows[g % ORIG][g / ORIG].
         // All loads of the tile are issued before the first LDS write (one HBM round trip per tile, not one
         // per element: the compiler cannot move a load above an LDS store of the loop before it).
-        constexpr int kPerThread = (ORIG * kRowLen + kThreads - 1) / kThreads;
-        float stage[kPerThread];
+        if constexpr (sizeof(TIn) == 2) {
+            // int16 mono: one aligned 32-bit load brings two samples (single 2-byte loads ran at half the rate of
+            // the float path).  Pairs are aligned in source-index space (clip starts are 4-byte aligned).
+            if (channels == 1 && (reinterpret_cast<uintptr_t>(x) & 3) == 0) {
+                const int base = ORIG * o0 - width;                 // source index of g = 0
+                const int e_base = base & ~1;                       // even (floor also for negative base)
+                constexpr int kPairs = (ORIG * kRowLen + 2 + 1) / 2;
+                constexpr int kPairsPerThread = (kPairs + kThreads - 1) / kThreads;
+                uint32_t stage2[kPairsPerThread];
 #pragma unroll
-        for (int i = 0; i < kPerThread; ++i) {
-            const int g = tid + i * kThreads;
-            const int src = ORIG * o0 + g - width;
-            stage[i] = (g < ORIG * kRowLen && src >= 0 && src < n) ? mono_at(x, n, channels, src) : 0.f;
-        }
+                for (int i = 0; i < kPairsPerThread; ++i) {
+                    const int e = e_base + 2 * (tid + i * kThreads);
+                    uint32_t w = 0;
+                    if (e >= 0 && e + 1 < n) w = *reinterpret_cast<const uint32_t*>(x + e);
+                    else if (e >= 0 && e < n) w = (uint16_t)x[e];
+                    else if (e + 1 >= 0 && e + 1 < n) w = (uint32_t)(uint16_t)x[e + 1] << 16;
+                    stage2[i] = w;
+                }
 #pragma unroll
-        for (int i = 0; i < kPerThread; ++i) {
-            const int g = tid + i * kThreads;
-            if (g < ORIG * kRowLen) rows[(g % ORIG) * kRowStride + g / ORIG] = stage[i];
+                for (int i = 0; i < kPairsPerThread; ++i) {
+                    const int g = e_base + 2 * (tid + i * kThreads) - base;
+                    const float lo = to_f32((int16_t)(stage2[i] & 0xffffu)), hi = to_f32((int16_t)(stage2[i] >> 16));
+                    if (g >= 0 && g < ORIG * kRowLen) rows[(g % ORIG) * kRowStride + g / ORIG] = lo;
+                    if (g + 1 >= 0 && g + 1 < ORIG * kRowLen) rows[((g + 1) % ORIG) * kRowStride + (g + 1) / ORIG] = hi;
+                }
+                __syncthreads();
+                goto staged;
+            }
         }
-        __syncthreads();
+        {
+            constexpr int kPerThread = (ORIG * kRowLen + kThreads - 1) / kThreads;
+            float stage[kPerThread];
+#pragma unroll
+            for (int i = 0; i < kPerThread; ++i) {
+                const int g = tid + i * kThreads;
+                const int src = ORIG * o0 + g - width;
+                stage[i] = (g < ORIG * kRowLen && src >= 0 && src < n) ? mono_at(x, n, channels, src) : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < kPerThread; ++i) {
+                const int g = tid + i * kThreads;
+                if (g < ORIG * kRowLen) rows[(g % ORIG) * kRowStride + g / ORIG] = stage[i];
+            }
+            __syncthreads();
+        }
+    staged:
         float acc[kOutPerThread] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < ORIG; ++r) {
@@ -132,8 +171,9 @@ __global__ __launch_bounds__(rs::kThreads) void decimate_peak_kernel(
     if ((tid & 63) == 0) atomicMax(&peak_keys[clip], __float_as_uint(peak));    // peak >= 0: bit order == value order
 }
 
+template <typename TIn>
 __global__ __launch_bounds__(256) void resample_generic_kernel(
-    const float* __restrict__ pcm_in, const int64_t* __restrict__ in_off, const int32_t* __restrict__ in_len,
+    const TIn* __restrict__ pcm_in, const int64_t* __restrict__ in_off, const int32_t* __restrict__ in_len,
     int channels, const ResamplePlanHeader* __restrict__ plan, float* __restrict__ pcm_out,
     const int64_t* __restrict__ out_off, int32_t* __restrict__ out_len, unsigned* __restrict__ peak_keys) {
     const int clip = blockIdx.y;
@@ -144,7 +184,7 @@ __global__ __launch_bounds__(256) void resample_generic_kernel(
     const int32_t* __restrict__ lo = reinterpret_cast<const int32_t*>(plan + 1);
     const int32_t* __restrict__ hi = lo + nw;
     const float* __restrict__ taps = reinterpret_cast<const float*>(hi + nw);
-    const float* __restrict__ x = pcm_in + in_off[clip];
+    const TIn* __restrict__ x = pcm_in + in_off[clip];
     float* __restrict__ y = pcm_out + out_off[clip];
     float peak = 0.f;
     for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += gridDim.x * blockDim.x) {
@@ -164,16 +204,17 @@ __global__ __launch_bounds__(256) void resample_generic_kernel(
 }
 
 // Same-rate path: optional mono mix / copy, and the per-clip peak.
+template <typename TIn>
 __global__ __launch_bounds__(256) void copy_peak_kernel(
-    const float* __restrict__ pcm_in, const int64_t* __restrict__ in_off, const int32_t* __restrict__ in_len,
+    const TIn* __restrict__ pcm_in, const int64_t* __restrict__ in_off, const int32_t* __restrict__ in_len,
     int channels, float* __restrict__ pcm_out, const int64_t* __restrict__ out_off, int32_t* __restrict__ out_len,
     unsigned* __restrict__ peak_keys) {
     const int clip = blockIdx.y;
     const int n = in_len[clip];
     if (blockIdx.x == 0 && threadIdx.x == 0) out_len[clip] = n;
-    const float* __restrict__ x = pcm_in + in_off[clip];
+    const TIn* __restrict__ x = pcm_in + in_off[clip];
     float* __restrict__ y = pcm_out + out_off[clip];
-    const bool store = (y != x) || channels != 1;
+    const bool store = (static_cast<const void*>(y) != static_cast<const void*>(x)) || channels != 1;
     float peak = 0.f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float v = mono_at(x, n, channels, i);
@@ -264,11 +305,12 @@ extern "C" int sttfe_preprocess_workspace_bytes(int batch, size_t* bytes) {
     return STTFE_OK;
 }
 
-extern "C" int sttfe_resample_peak(const float* pcm_in, const int64_t* in_offsets, const int32_t* in_lengths,
-                                   int batch, int channels, int64_t max_in_length,
-                                   const void* dev_plan, const void* host_plan,
-                                   float* pcm_out, const int64_t* out_offsets, int32_t* out_lengths,
-                                   void* workspace, size_t workspace_bytes, void* stream_) {
+template <typename TIn>
+static int resample_peak_impl(const TIn* pcm_in, const int64_t* in_offsets, const int32_t* in_lengths,
+                              int batch, int channels, int64_t max_in_length,
+                              const void* dev_plan, const void* host_plan,
+                              float* pcm_out, const int64_t* out_offsets, int32_t* out_lengths,
+                              void* workspace, size_t workspace_bytes, void* stream_) {
     if (batch < 0 || channels < 1 || channels > 64 || max_in_length < 0) return STTFE_E_INVALID_ARG;
     if (batch == 0) return STTFE_OK;
     if (!pcm_in || !in_offsets || !in_lengths || !pcm_out || !out_offsets || !out_lengths || !workspace)
@@ -287,7 +329,7 @@ extern "C" int sttfe_resample_peak(const float* pcm_in, const int64_t* in_offset
     if (!dev_plan) {
         int bx = (int)((max_in_length + 256 * 8 - 1) / (256 * 8));
         bx = bx < 1 ? 1 : (bx > 1024 ? 1024 : bx);
-        hipLaunchKernelGGL(copy_peak_kernel, dim3(bx, batch), dim3(256), 0, stream, pcm_in, in_offsets, in_lengths,
+        hipLaunchKernelGGL(copy_peak_kernel<TIn>, dim3(bx, batch), dim3(256), 0, stream, pcm_in, in_offsets, in_lengths,
                            channels, pcm_out, out_offsets, out_lengths, keys);
     } else {
         const auto* hp = reinterpret_cast<const ResamplePlanHeader*>(host_plan);
@@ -303,7 +345,7 @@ extern "C" int sttfe_resample_peak(const float* pcm_in, const int64_t* in_offset
             bx = bx < 1 ? 1 : bx;
             const dim3 grid(bx, batch), block(rs::kThreads);
 #define STTFE_LAUNCH_DECIMATE(O)                                                                             \
-    hipLaunchKernelGGL(decimate_peak_kernel<O>, grid, block, 0, stream, pcm_in, in_offsets, in_lengths,      \
+    hipLaunchKernelGGL((decimate_peak_kernel<O, TIn>), grid, block, 0, stream, pcm_in, in_offsets, in_lengths,      \
                        channels, dp, pcm_out, out_offsets, out_lengths, keys, tiles_per_block)
             switch (hp->orig_rate) {
                 case 2: STTFE_LAUNCH_DECIMATE(2); break;
@@ -315,12 +357,30 @@ extern "C" int sttfe_resample_peak(const float* pcm_in, const int64_t* in_offset
         } else {
             int bx = (int)((max_out + 256 * 4 - 1) / (256 * 4));
             bx = bx < 1 ? 1 : (bx > 2048 ? 2048 : bx);
-            hipLaunchKernelGGL(resample_generic_kernel, dim3(bx, batch), dim3(256), 0, stream, pcm_in, in_offsets,
+            hipLaunchKernelGGL(resample_generic_kernel<TIn>, dim3(bx, batch), dim3(256), 0, stream, pcm_in, in_offsets,
                                in_lengths, channels, dp, pcm_out, out_offsets, out_lengths, keys);
         }
     }
     if (hip_failed(hipGetLastError(), "resample kernel launch")) return STTFE_E_LAUNCH;
     return STTFE_OK;
+}
+
+extern "C" int sttfe_resample_peak(const float* pcm_in, const int64_t* in_offsets, const int32_t* in_lengths,
+                                   int batch, int channels, int64_t max_in_length,
+                                   const void* dev_plan, const void* host_plan,
+                                   float* pcm_out, const int64_t* out_offsets, int32_t* out_lengths,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    return resample_peak_impl<float>(pcm_in, in_offsets, in_lengths, batch, channels, max_in_length, dev_plan, host_plan,
+                                     pcm_out, out_offsets, out_lengths, workspace, workspace_bytes, stream);
+}
+
+extern "C" int sttfe_resample_peak_s16(const int16_t* pcm_in, const int64_t* in_offsets, const int32_t* in_lengths,
+                                       int batch, int channels, int64_t max_in_length,
+                                       const void* dev_plan, const void* host_plan,
+                                       float* pcm_out, const int64_t* out_offsets, int32_t* out_lengths,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    return resample_peak_impl<int16_t>(pcm_in, in_offsets, in_lengths, batch, channels, max_in_length, dev_plan,
+                                       host_plan, pcm_out, out_offsets, out_lengths, workspace, workspace_bytes, stream);
 }
 
 extern "C" int sttfe_normalize_trim(float* pcm, int64_t* offsets, int32_t* lengths, int batch,

@@ -74,39 +74,63 @@ class ResamplePlan:
         return rows[:, :self.n_taps].copy()
 
 
-def pack_planar(clips: Sequence, device: torch.device):
-    """Clips of identical channel count -> (pcm, offsets int64, lengths int32, host lengths, channels).
+def _as_planar(c):
+    """One clip -> ((channels, n) array or tensor, is_int16).  int16 stays int16 (decoded PCM), the rest is float32."""
+    if torch.is_tensor(c):
+        a = c.detach()
+        a = a.reshape(1, -1) if a.dim() == 1 else a.reshape(a.shape[0], -1)
+        return (a, True) if a.dtype == torch.int16 else (a.to(torch.float32), False)
+    a = np.asarray(c)
+    s16 = a.dtype == np.int16
+    if not s16:
+        a = a.astype(np.float32, copy=False)
+    return (a.reshape(1, -1) if a.ndim == 1 else a.reshape(a.shape[0], -1)), s16
 
-    Clip b is stored as ``channels`` planar rows of ``lengths[b]`` samples (what
-    ``sttfe_resample_peak`` expects).  Host arrays go through one pinned staging buffer.
-    """
-    arrs, lens, chans = [], [], None
-    for c in clips:
-        if torch.is_tensor(c):
-            a = c.detach()
-            a = a.reshape(1, -1) if a.dim() == 1 else a.reshape(a.shape[0], -1)
-            a = a.to(torch.float32)
-        else:
-            a = np.asarray(c, dtype=np.float32)
-            a = a.reshape(1, -1) if a.ndim == 1 else a.reshape(a.shape[0], -1)
+
+def _layout(arrs):
+    lens, chans = [], None
+    for a in arrs:
         if chans is None:
             chans = int(a.shape[0])
         elif chans != int(a.shape[0]):
             raise ValueError("pack_planar: all clips of one call must have the same channel count")
-        arrs.append(a)
         lens.append(int(a.shape[1]))
     starts, total = [], 0
     for n in lens:
         starts.append(total)
         total += (chans * n + _ALIGN - 1) // _ALIGN * _ALIGN
-    pcm = torch.empty(total + _ALIGN, dtype=torch.float32, device=device)
+    return lens, chans or 1, starts, total
+
+
+def _fill_stage(stage: torch.Tensor, arrs, idx, starts, lens, chans):
+    sn = stage.numpy()
+    for i in idx:
+        a = arrs[i].numpy() if torch.is_tensor(arrs[i]) else arrs[i]
+        sn[starts[i]:starts[i] + chans * lens[i]] = a.reshape(-1)
+
+
+def pack_planar(clips: Sequence, device: torch.device):
+    """Clips of identical channel count -> (pcm, offsets int64, lengths int32, host lengths, channels).
+
+    Clip b is stored as ``channels`` planar rows of ``lengths[b]`` samples (what ``sttfe_resample_peak``
+    expects).  Host arrays go through one pinned staging buffer.  When every clip is int16 (decoded PCM) the
+    buffer stays int16 -- half the bytes over PCIe -- and ``sttfe_resample_peak_s16`` converts on the fly;
+    mixed input is converted to float32 on the host (x / 32768).
+    """
+    pairs = [_as_planar(c) for c in clips]
+    s16 = bool(pairs) and all(f for _, f in pairs)
+    arrs = []
+    for a, f in pairs:
+        if f and not s16:
+            a = (a.to(torch.float32) if torch.is_tensor(a) else a.astype(np.float32)) / 32768.0
+        arrs.append(a)
+    dtype = torch.int16 if s16 else torch.float32
+    lens, chans, starts, total = _layout(arrs)
+    pcm = torch.empty(total + _ALIGN, dtype=dtype, device=device)
     host_idx = [i for i, a in enumerate(arrs) if not torch.is_tensor(a) or not a.is_cuda]
     if host_idx:
-        stage = torch.empty(total + _ALIGN, dtype=torch.float32, pin_memory=torch.cuda.is_available())
-        sn = stage.numpy()
-        for i in host_idx:
-            a = arrs[i].numpy() if torch.is_tensor(arrs[i]) else arrs[i]
-            sn[starts[i]:starts[i] + chans * lens[i]] = a.reshape(-1)
+        stage = torch.empty(total + _ALIGN, dtype=dtype, pin_memory=torch.cuda.is_available())
+        _fill_stage(stage, arrs, host_idx, starts, lens, chans)
         if len(host_idx) == len(arrs):
             pcm.copy_(stage, non_blocking=True)
         else:
@@ -119,6 +143,62 @@ def pack_planar(clips: Sequence, device: torch.device):
     offsets = torch.tensor(starts, dtype=torch.int64).to(device, non_blocking=True)
     lengths = torch.tensor(lens, dtype=torch.int32).to(device, non_blocking=True)
     return pcm, offsets, lengths, lens, chans
+
+
+class PinnedIngestRing:
+    """Decoded-PCM ingest: a ring of pinned staging buffers and a copy stream.
+
+    DataLoader workers only decode (``torchaudio.load``, reference ``src/data.py:313``; ``pin_memory`` /
+    ``num_workers`` at ``train.py:1457-1464``); the main process calls ``submit(clips)`` as batches arrive --
+    one host memcpy into the next pinned slot and one asynchronous H2D copy on the ring's own stream -- and
+    ``take(ticket)`` when the GPU front-end is ready for the batch: the compute stream then waits on the copy's
+    event, not the host.  With ``slots`` >= 2 the copy of batch k+1 runs under the kernels of batch k.
+    int16 clips stay int16 on the wire (see ``pack_planar``).
+    """
+
+    def __init__(self, device: Union[str, torch.device], slots: int = 3):
+        self.device = _resolve_device(device)
+        self.stream = torch.cuda.Stream(self.device)
+        self._slots: List[Optional[torch.Tensor]] = [None] * max(int(slots), 1)
+        self._events: List[Optional[torch.cuda.Event]] = [None] * len(self._slots)
+        self._next = 0
+
+    def submit(self, clips: Sequence):
+        """Host clips (numpy / CPU tensors, all int16 or all float) -> ticket for ``take``."""
+        pairs = [_as_planar(c) for c in clips]
+        s16 = bool(pairs) and all(f for _, f in pairs)
+        arrs = [a if (s16 or not f) else (a.to(torch.float32) if torch.is_tensor(a) else a.astype(np.float32)) / 32768.0
+                for a, f in pairs]
+        dtype = torch.int16 if s16 else torch.float32
+        lens, chans, starts, total = _layout(arrs)
+        k = self._next
+        self._next = (k + 1) % len(self._slots)
+        if self._events[k] is not None:
+            self._events[k].synchronize()          # the slot's previous copy has left the pinned buffer
+        slot = self._slots[k]
+        if slot is None or slot.dtype != dtype or slot.numel() < total + _ALIGN:
+            slot = torch.empty(max(total + _ALIGN, 1), dtype=dtype, pin_memory=True)
+            self._slots[k] = slot
+        _fill_stage(slot, arrs, range(len(arrs)), starts, lens, chans)
+        with torch.cuda.stream(self.stream):
+            pcm = torch.empty(total + _ALIGN, dtype=dtype, device=self.device)
+            pcm.copy_(slot[:total + _ALIGN], non_blocking=True)
+            offsets = torch.tensor(starts, dtype=torch.int64).to(self.device, non_blocking=True)
+            lengths = torch.tensor(lens, dtype=torch.int32).to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._events[k] = ev
+        return (pcm, offsets, lengths, lens, chans, ev)
+
+    def take(self, ticket):
+        """-> (pcm, offsets, lengths, host_lengths, channels), ready for ``GpuAudioPreprocessor.run`` on the
+        current stream."""
+        pcm, offsets, lengths, lens, chans, ev = ticket
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)
+        for t in (pcm, offsets, lengths):
+            t.record_stream(cur)                   # allocated on the copy stream, consumed on the compute stream
+        return pcm, offsets, lengths, lens, chans
 
 
 class GpuAudioPreprocessor:
@@ -175,7 +255,10 @@ class GpuAudioPreprocessor:
         for n in out_lens:
             starts.append(total)
             total += (n + _ALIGN - 1) // _ALIGN * _ALIGN
-        alias = plan is None and channels == 1
+        s16 = pcm_in.dtype == torch.int16
+        if not s16 and pcm_in.dtype != torch.float32:
+            raise TypeError("packed PCM must be float32 or int16")
+        alias = plan is None and channels == 1 and not s16
         if alias:
             pcm_out, out_offsets = pcm_in, in_offsets.clone()
         else:
@@ -188,12 +271,13 @@ class GpuAudioPreprocessor:
         stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
         max_in = max(host_lengths) if B else 0
         with torch.cuda.device(device):
-            _lib.check(L.sttfe_resample_peak(_lib.ptr(pcm_in), _lib.ptr(in_offsets), _lib.ptr(in_lengths), B,
-                                             int(channels), int(max_in),
-                                             _lib.ptr(plan.on(device)) if plan else None,
-                                             _lib.ptr(plan.host) if plan else None,
-                                             _lib.ptr(pcm_out), _lib.ptr(out_offsets), _lib.ptr(out_lengths),
-                                             _lib.ptr(ws), ws.numel(), stream), "sttfe_resample_peak")
+            entry = L.sttfe_resample_peak_s16 if s16 else L.sttfe_resample_peak
+            _lib.check(entry(_lib.ptr(pcm_in), _lib.ptr(in_offsets), _lib.ptr(in_lengths), B,
+                             int(channels), int(max_in),
+                             _lib.ptr(plan.on(device)) if plan else None,
+                             _lib.ptr(plan.host) if plan else None,
+                             _lib.ptr(pcm_out), _lib.ptr(out_offsets), _lib.ptr(out_lengths),
+                             _lib.ptr(ws), ws.numel(), stream), "sttfe_resample_peak")
             _lib.check(L.sttfe_normalize_trim(_lib.ptr(pcm_out), _lib.ptr(out_offsets), _lib.ptr(out_lengths), B,
                                               int(max(out_lens) if B else 0), int(self.normalize),
                                               int(self.trim_silence), ctypes.c_float(self.silence_threshold),
