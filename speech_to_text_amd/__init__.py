@@ -9,6 +9,7 @@ __version__ = "0.1.0"
 from .augment import GpuWaveformAugmenter, SpecAugmentSampler, WaveformAugmentSampler, WaveformDraw  # noqa: F401
 from .config import AugmentationConfig, DataConfig  # noqa: F401
 from .data import AudioCollator, GpuFrontEnd  # noqa: F401
-from .preprocess import GpuAudioPreprocessor, PackedAudio, ResamplePlan  # noqa: F401
+from .feature_cache import FeatureCacheDataset, FeatureCacheWriter  # noqa: F401
+from .preprocess import GpuAudioPreprocessor, PackedAudio, PinnedIngestRing, ResamplePlan  # noqa: F401
 from .processors import (BatchFeature, HipSpeech2TextFeatureExtractor, HipWhisperFeatureExtractor,  # noqa: F401
                          TorchWhisperFeatureExtractor, pack_clips)

@@ -129,3 +129,25 @@ def test_whisper_train_batch_with_waveform_and_spec_augmentation():
         e = S.apply_masks(whisper_features([W.apply_time_domain(c, d)], 80)[0], masks)
         assert np.abs(got[b] - e).max() <= 1e-4, (b, d.speed_factor, d.gain, d.fade_samples)
     assert len(kinds) == 4                                            # the seed exercises every built stage
+
+
+def test_feature_cache_round_trip_of_gpu_features(tmp_path):
+    """Offline precompute (BASELINE config 5): GPU features -> cache on disk -> Dataset == the features themselves;
+    the cache keeps only the computed tiles, so this also pins `whisper_computed_frames` to the kernel's tiling."""
+    from speech_to_text_amd.feature_cache import FeatureCacheDataset, FeatureCacheWriter
+    from speech_to_text_amd.processors import HipWhisperFeatureExtractor
+    from speech_to_text_amd.sharding import precompute_corpus
+    lens = [16000, 7480, 7481, 480000, 100000, 1, 52000]
+    clips = synth_batch(35, lens)
+    fe = HipWhisperFeatureExtractor(80, device=DEV)
+    direct = fe(clips, sampling_rate=16000, return_tensors="pt").input_features
+    w = FeatureCacheWriter(str(tmp_path), "whisper", 80, shard_clips=3)
+    for idx, feats in precompute_corpus(lens, 0, 1, 4, lambda ids: fe([clips[i] for i in ids], sampling_rate=16000,
+                                                                      return_tensors="pt").input_features):
+        w.add_batch(idx, feats, [lens[i] for i in idx], texts=[f"t{i}" for i in idx])
+    w.close()
+    ds = FeatureCacheDataset(str(tmp_path))
+    assert len(ds) == len(lens)
+    for i in range(len(lens)):
+        assert ds[i]["id"] == i and ds[i]["text"] == f"t{i}"
+        assert torch.equal(ds[i]["input_features"], direct[i].cpu()), i
