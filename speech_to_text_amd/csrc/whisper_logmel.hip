@@ -618,12 +618,21 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     // ---- fill: rows are n_frames floats long, n_frames % 4 == 0, pad_frame % 4 == 0: aligned 16-byte stores
     if (pad_frame < n_frames) {
         const int quads = (n_frames - pad_frame) >> 2;
-        for (int mel = row0; mel < n_mels; mel += row_step) {
+        // the workgroup's rows x quads as one index space, so that every trip but the last keeps all 256 lanes busy
+        const int n_quads = rows * quads;
+        int r = threadIdx.x / quads, q = threadIdx.x - r * quads;
+        const int dr = blockDim.x / quads, dq = blockDim.x - dr * quads;
+        for (int item = threadIdx.x; item < n_quads; item += blockDim.x) {
+            const int mel = row0 + r * row_step;
             const bool mmasked = ((mel < 64 ? melmask_lo >> mel : melmask_hi >> (mel - 64)) & 1ull);
             const float c = mmasked ? 0.0f : pad_y;
-            const f32x4 c4 = {c, c, c, c};
-            f32x4* rowp = reinterpret_cast<f32x4*>(o + (size_t)mel * n_frames + pad_frame);
-            for (int q = threadIdx.x; q < quads; q += blockDim.x) rowp[q] = c4;
+            reinterpret_cast<f32x4*>(o + (size_t)mel * n_frames + pad_frame)[q] = f32x4{c, c, c, c};
+            r += dr;
+            q += dq;
+            if (q >= quads) {
+                q -= quads;
+                ++r;
+            }
         }
         if (nt != 0) {                                             // then the few time-masked columns are zeroed
             __syncthreads();
