@@ -115,13 +115,21 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
                          "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # STTFE_BENCH_REHEARSE=1: rehearsal of the N > 1 code path on a one-GPU box -- the ranks share GPU 0 and the
+    # barrier / reductions go over gloo (RCCL refuses two ranks on one device).  Never set for a real measurement.
+    rehearse = os.environ.get("STTFE_BENCH_REHEARSE") == "1"
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
+    red_device = torch.device("cpu") if rehearse else device
 
     from speech_to_text_amd import _lib
     from speech_to_text_amd.augment import SpecAugmentSampler
@@ -231,10 +239,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        a = torch.tensor([audio_seconds], dtype=torch.float64, device=device)
+        a = torch.tensor([audio_seconds], dtype=torch.float64, device=red_device)
         dist.all_reduce(a, op=dist.ReduceOp.SUM)
         audio_total = float(a.item())
     else:
