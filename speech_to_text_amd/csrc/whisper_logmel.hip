@@ -198,9 +198,10 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         }
         __syncthreads();
     }
-    // Run length (tiles per item).  Long runs are measured faster per tile (1.03 ms at 21 tiles against 1.22 ms at 7
-    // for 1024 full-length clips), short ones keep the workgroups balanced when clip lengths differ: a third of the
-    // clip for (near-)uniform batches, a fifth of the longest clip otherwise.
+    // Run length (tiles per item).  With persistent workgroups the run length does not change the time per tile
+    // (7 and 21 tiles both 1.03 ms for 1024 full-length clips once the clocks have settled); short runs keep the
+    // workgroups balanced when clip lengths differ (11-tile runs cost +40 % on Common-Voice-length clips): a third
+    // of the clip for (near-)uniform batches, a fifth of the longest clip otherwise.
     const int max_tiles = min(n_tiles, first_pad_tile_of(max_len));
     if (tiles_per_block <= 0) {
         const bool uniform = first_pad_tile_of(min_len) + 1 >= max_tiles;
