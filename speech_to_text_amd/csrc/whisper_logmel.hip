@@ -313,12 +313,10 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         wave_lds_sync();
     };
     auto s2_read = [&](f32x4 (&r4)[10]) {
+        // the idle lanes 60..63 read rows 0..3 of pair 0 too (same addresses as lanes 0..3: a broadcast, no bank
+        // conflict); predicating them off cost 40 v_mov per pass to give their registers a defined value
 #pragma unroll
-        for (int q = 0; q < 10; ++q) r4[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (active) {
-#pragma unroll
-            for (int q = 0; q < 10; ++q) r4[q] = slab_r[q];
-        }
+        for (int q = 0; q < 10; ++q) r4[q] = slab_r[q];
     };
     auto s2_math = [&](const f32x4 (&r4)[10], f2 (&y)[20]) {
         f2 v[20];
