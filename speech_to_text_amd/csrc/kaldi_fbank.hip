@@ -22,6 +22,7 @@
 //   SpecAugment masks <- 0, attention mask written (int32 or int64).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/sttfe.h"
 #include "fft_core.h"
@@ -91,9 +92,47 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     const int tile_end = min(tile_begin + tiles_per_block, n_tiles);
     if (tile_begin >= tile_end) return;
 
-    // zero the slabs once (pad cells of the panel rows are read by zero-weight MFMA steps and must be
-    // finite), stage the tables
-    for (int i = tid; i < kWinOff; i += kThreads) smem[i] = 0.f;
+    // stage-1 lane roles: half-wave h = pair within the round, n2 = column
+    const int h = lane >> 5, n2 = lane & 31;
+    // PCM of one pass (2 frame pairs per wave): x[n] and x[n - 1] (pre-emphasis) for frame a = rows 0..12 and
+    // frame b = rows 5..17 of x[base + 32 m].  Requested a whole tile ahead, so that the HBM latency lies under
+    // the mel phase of the previous tile (and, for the first tile, under the table staging).
+    auto load_pass = [&](int t0, int r, float (&raw)[18], float (&prv)[18]) {
+        const int pair = 2 * r + h;
+        const int fa = t0 + wave * kFramesPerWave + 2 * pair;
+        const int base = kHop * fa + n2;
+        // last sample any lane of this wave may touch (frame b of the last pair, m = 17, n2 = 31)
+        const bool interior = (kHop * (t0 + wave * kFramesPerWave + kFramesPerWave - 1) + kFrame + 16 <= n_valid);
+        if (interior) {
+#pragma unroll
+            for (int m = 0; m < 18; ++m) {
+                const int idx = base + 32 * m;
+                raw[m] = x[idx];
+                prv[m] = x[idx > 0 ? idx - 1 : 0];
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 18; ++m) {
+                const int idx = base + 32 * m;
+                raw[m] = (idx < n_valid) ? x[idx] : 0.0f;
+                prv[m] = (idx - 1 < n_valid) ? x[idx > 0 ? idx - 1 : 0] : 0.0f;
+            }
+        }
+    };
+    float raw0[18], prv0[18], raw1[18], prv1[18];
+    load_pass(tile_begin * kTileFrames, 0, raw0, prv0);
+    load_pass(tile_begin * kTileFrames, 1, raw1, prv1);
+
+    // The pad cells of the panel rows are read by zero-weight MFMA steps and must be finite.  A panel row aliases
+    // the wave's exchange slab, whose cells are all rewritten with finite values by every tile except the pad
+    // column of its [k1][n2] rows (33rd complex of each) and the tail of the region: zero exactly those, once.
+    for (int i = tid; i < kWaves * 4 * 16; i += kThreads) {
+        const int w = i >> 6, p = (i >> 4) & 3, row = i & 15;
+        float* cell = smem + w * kSlabFloats + 2 * (p * kPairStride + row * kRowStride + 32);
+        cell[0] = 0.f;
+        cell[1] = 0.f;
+    }
+    for (int i = tid; i < kWaves * 16; i += kThreads) smem[(i >> 4) * kSlabFloats + 4 * kPairStride * 2 + (i & 15)] = 0.f;
     for (int i = tid; i < 400; i += kThreads) smem[kWinOff + i] = tab->window[i];
     for (int i = tid; i < 1024; i += kThreads) smem[kTwOff + i] = tab->twiddle[i];
     {
@@ -101,15 +140,8 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
         const int na = min(tab->afrag_floats, kMaxAfragFloats);
         for (int i = tid; i < na; i += kThreads) smem[kAfragOff + i] = afrag_g[i];
         int* desc = reinterpret_cast<int*>(smem + kDescOff);
-        if (tid < kWaves * kMaxUnitsPerWave) {
-            const int w = tid / kMaxUnitsPerWave, u = tid - w * kMaxUnitsPerWave;
-            const int code = tab->plan.wave_units[w][u], mt = code & 0xff;
-            const bool ok = u < tab->plan.wave_nunits[w];
-            desc[4 * tid + 0] = ok ? tab->plan.kstart[mt] : 0;
-            desc[4 * tid + 1] = ok ? tab->plan.nsteps[mt] : 0;
-            desc[4 * tid + 2] = ok ? tab->plan.aoff[mt] : 0;
-            desc[4 * tid + 3] = code;
-        }
+        if (tid < kWaves * kMaxUnitsPerWave)
+            reinterpret_cast<int4k*>(desc)[tid] = reinterpret_cast<const int4k*>(&tab->plan.desc[0][0][0])[tid];
         if (tid < kWaves) desc[4 * kWaves * kMaxUnitsPerWave + tid] = tab->plan.wave_nunits[tid];
     }
     __syncthreads();
@@ -125,8 +157,6 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     float* __restrict__ out_clip = out + (size_t)clip * t_max * n_mels;
     double* __restrict__ st = stats + (size_t)clip * 2 * n_mels;
 
-    // stage-1 lane roles: half-wave h = pair within the round, n2 = column
-    const int h = lane >> 5, n2 = lane & 31;
     // stage-2 lane roles: q = pair, k1 = row
     const int q = lane >> 4, k1 = lane & 15;
     const int partner = q * 16 + ((16 - k1) & 15);
@@ -144,30 +174,8 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
 
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const int t0 = tile * kTileFrames;
-        // last sample any lane of this wave may touch (frame b of the last pair, m = 17, n2 = 31)
-        const bool interior = (kHop * (t0 + wave * kFramesPerWave + kFramesPerWave - 1) + kFrame + 16 <= n_valid);
-
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        auto stage1 = [&](int r, const float (&raw)[18], const float (&prv)[18]) {
             const int pair = 2 * r + h;
-            const int fa = t0 + wave * kFramesPerWave + 2 * pair;
-            const int base = kHop * fa + n2;
-            float raw[18], prv[18];
-            if (interior) {
-#pragma unroll
-                for (int m = 0; m < 18; ++m) {
-                    const int idx = base + 32 * m;
-                    raw[m] = x[idx];
-                    prv[m] = x[idx > 0 ? idx - 1 : 0];
-                }
-            } else {
-#pragma unroll
-                for (int m = 0; m < 18; ++m) {
-                    const int idx = base + 32 * m;
-                    raw[m] = (idx < n_valid) ? x[idx] : 0.0f;
-                    prv[m] = (idx - 1 < n_valid) ? x[idx > 0 ? idx - 1 : 0] : 0.0f;
-                }
-            }
             // window column and twiddles: all LDS reads are issued before the first slab write (the compiler
             // cannot move an LDS read above an LDS write of the same array)
             float wv[13];
@@ -214,7 +222,9 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
             slab[0] = y[0];
 #pragma unroll
             for (int kk = 1; kk < 16; ++kk) slab[kk * kRowStride] = cmul(y[kk], tw[kk]);
-        }
+        };
+        stage1(0, raw0, prv0);
+        stage1(1, raw1, prv1);
         wave_lds_sync2();
 
         // ---------------- stage 2: 32-point DFT over n2 ------------------------------------------
@@ -243,6 +253,11 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
                 prow[256] = 4.0f * y[16].x * y[16].x;
                 prow[kPStride + 256] = 4.0f * y[16].y * y[16].y;
             }
+        }
+        // next tile's PCM: requested now (few live registers from here on), lands during the mel phase
+        if (tile + 1 < tile_end) {
+            load_pass(t0 + kTileFrames, 0, raw0, prv0);
+            load_pass(t0 + kTileFrames, 1, raw1, prv1);
         }
         __syncthreads();
 
@@ -408,7 +423,12 @@ extern "C" int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, 
     const auto* tab = reinterpret_cast<const KaldiTablesHeader*>(dev_tables);
     const int n_tiles = (t_max + kaldi::kTileFrames - 1) / kaldi::kTileFrames;
     // one workgroup per CU: runs as long as possible while the batch still gives >= 2 rounds of workgroups
-    int runs = (512 + batch - 1) / batch;
+    static const int runs_env = [] {
+        const char* e = getenv("STTFE_KALDI_RUNS");                // tuning knob: runs per clip (0 / unset = automatic)
+        const int v = e ? atoi(e) : 0;
+        return v < 0 ? 0 : v;
+    }();
+    int runs = runs_env ? runs_env : (512 + batch - 1) / batch;
     runs = runs < 1 ? 1 : (runs > n_tiles ? n_tiles : runs);
     const int tiles_per_block = (n_tiles + runs - 1) / runs;
     const int bx = (n_tiles + tiles_per_block - 1) / tiles_per_block;
