@@ -104,3 +104,45 @@ def test_specaugment_masks_fused(fe80):
             else:
                 exp[b, s:e, :] = 0.0
     assert torch.equal(got, exp)
+
+
+def test_work_item_scheduling_is_invisible(fe80):
+    """The persistent kernel hands (tile run, clip) items to its workgroups through a ticket counter and picks the
+    run length itself; whatever the run length and the batch composition, every clip must get the same bits."""
+    from speech_to_text_amd import _lib
+    L = _lib.lib()
+    lens = [480000, 16000, 1, 7480, 7481, 250000, 480000, 52001, 300, 96000, 123457, 31999]
+    clips = synth_batch(77, lens)
+    ref = fe80(clips, sampling_rate=16000, return_tensors="pt").input_features.clone()
+    try:
+        for tpb in (1, 2, 5, 13, 63):
+            assert L.sttfe_set_whisper_tiles_per_block(tpb) == 0
+            got = fe80(clips, sampling_rate=16000, return_tensors="pt").input_features
+            assert torch.equal(got, ref), tpb
+    finally:
+        L.sttfe_set_whisper_tiles_per_block(0)
+    assert L.sttfe_set_whisper_tiles_per_block(64) == -1 and L.sttfe_set_whisper_tiles_per_block(-1) == -1
+    # one clip at a time == the batch; reversed batch == reversed output
+    one = fe80(clips[5], sampling_rate=16000, return_tensors="pt").input_features
+    assert torch.equal(one[0], ref[5])
+    rev = fe80(clips[::-1], sampling_rate=16000, return_tensors="pt").input_features
+    assert torch.equal(rev.flip(0), ref)
+
+
+def test_very_large_batch_of_short_clips():
+    """> 16384 clips: the kernel skips its own length scan (run length from the frame count alone) -- same bits as
+    the same clips fed in two halves.  One mel bin keeps the output at 240 MB."""
+    from speech_to_text_amd.processors import HipWhisperFeatureExtractor
+    fe = HipWhisperFeatureExtractor(1, device="cuda:0")
+    B, n = 20000, 1600
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    pcm = (torch.rand(B * n, generator=g, device="cuda:0") - 0.5) * 0.2
+    off = torch.arange(B, dtype=torch.int64, device="cuda:0") * n
+    ln = torch.randint(1, n + 1, (B,), generator=g, device="cuda:0", dtype=torch.int32)
+    full = fe.extract(pcm, off, ln).clone()
+    assert full.shape == (B, 1, 3000)
+    half = B // 2
+    a = fe.extract(pcm, off[:half], ln[:half]).clone()
+    b = fe.extract(pcm, off[half:], ln[half:])
+    assert torch.equal(full[:half], a) and torch.equal(full[half:], b)
+    assert torch.isfinite(full).all()
