@@ -266,7 +266,6 @@ class GpuWaveformAugmenter:
             out_offsets = torch.tensor(starts, dtype=torch.int64).to(device, non_blocking=True)
             out_lengths = torch.empty(B, dtype=torch.int32, device=device)
             ws_bytes = ctypes.c_size_t()
-            moved = set()
             groups = dict(speed_groups)
             rest = [b for b in range(B) if not any(b in g for g in speed_groups.values())]
             if rest:
@@ -286,9 +285,7 @@ class GpuWaveformAugmenter:
                                                      _lib.ptr(pcm_out), _lib.ptr(o_off), _lib.ptr(o_len),
                                                      _lib.ptr(ws), ws.numel(), stream), "sttfe_resample_peak")
                 out_lengths[sel] = o_len
-                moved.update(idx)
-            durations_rate = packed.sample_rate
-            out = PackedAudio(pcm_out, out_offsets, out_lengths, new_lens, durations_rate, keep)
+            out = PackedAudio(pcm_out, out_offsets, out_lengths, new_lens, packed.sample_rate, keep)
             run(out, AUG_GAIN | AUG_FADE)
         for b, d in enumerate(draws):
             if d.fade_samples is not None and d.fade_samples > out.host_lengths[b]:
