@@ -574,25 +574,29 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     using namespace wh;
     const int clip = blockIdx.y;
     const int row0 = blockIdx.x, row_step = gridDim.x;
+    // Everything the workgroup needs from memory is requested in ONE batch (length, max key, the per-tile min keys,
+    // the clip's mask table -> LDS): with four dependent round trips per workgroup this kernel was latency-bound
+    // (0.10 ms for 32 k workgroups that find nothing to clamp).
+    __shared__ unsigned long long s_flags;
+    __shared__ int32_t s_masks[24];
+    const int nm = mask_tbl ? n_masks : 0;
     int n_valid = lengths[clip];
+    const unsigned kmax = keys[(size_t)clip * kKeysPerClip];
+    unsigned kmin_raw = 0xffffffffu;
+    if (threadIdx.x < kKeysPerClip - 1) kmin_raw = keys[(size_t)clip * kKeysPerClip + 1 + threadIdx.x];
+    if ((int)threadIdx.x < 3 * nm) s_masks[threadIdx.x] = mask_tbl[(size_t)clip * n_masks * 3 + threadIdx.x];
     n_valid = n_valid < 0 ? 0 : (n_valid > kMaxSamples ? kMaxSamples : n_valid);
     const int n_tiles = (n_frames + kTileFrames - 1) / kTileFrames;
     const int first_pad_tile = min(n_tiles, (n_valid + kNfft / 2 + kHop * kTileFrames - 1) / (kHop * kTileFrames));
     const int pad_frame = min(n_frames, first_pad_tile * kTileFrames);         // first frame of the constant region
-    const unsigned kmax = keys[(size_t)clip * kKeysPerClip];
     const float lmax = kmax ? key_to_float(kmax) : -10.0f;        // no computed tile at all: log10(1e-10)
     const float floor_lg = lmax - 8.0f;
     const float floor_y = (floor_lg + 4.0f) * 0.25f;
     const float pad_y = fmaxf((-10.0f + 4.0f) * 0.25f, floor_y);
 
     // tiles of the clip with something below the floor (n_tiles <= 63: one 64-bit word)
-    __shared__ unsigned long long s_flags;
     if (threadIdx.x < 64) {
-        bool flag = false;
-        if ((int)threadIdx.x < first_pad_tile) {
-            const unsigned kmin = ~keys[(size_t)clip * kKeysPerClip + 1 + threadIdx.x];
-            flag = key_to_float(kmin) < floor_lg;
-        }
+        const bool flag = (int)threadIdx.x < first_pad_tile && key_to_float(~kmin_raw) < floor_lg;
         const unsigned long long bal = __ballot(flag);
         if (threadIdx.x == 0) s_flags = bal;
     }
@@ -600,8 +604,7 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     const unsigned long long flags = s_flags;
     if (pad_frame >= n_frames && flags == 0ull) return;           // the usual full-length clip: nothing to do
 
-    const int32_t* __restrict__ cm = mask_tbl ? mask_tbl + (size_t)clip * n_masks * 3 : nullptr;
-    const int nm = cm ? n_masks : 0;
+    const int32_t* cm = s_masks;
     const uint64_t melmask_lo = mask_bits(cm, nm, STTFE_AXIS_FREQ, 0, 64);
     const uint64_t melmask_hi = mask_bits(cm, nm, STTFE_AXIS_FREQ, 64, 64);
     int ts[8], te[8], nt = 0;                                      // time-axis masks of the clip
