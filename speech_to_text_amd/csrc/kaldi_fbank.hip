@@ -5,7 +5,7 @@
 // HF:audio_utils.py:953-1017) as reached from the reference at src/data.py:346-358, plus the
 // zero padding / attention mask / transpose of the collator (src/data.py:468-496).
 //
-// Kernel 1 (kaldi_fbank): one 256-thread workgroup (4 waves) per 32-frame tile of one clip.
+// Kernel 1 (kaldi_fbank): persistent 256-thread workgroups (4 waves) walking (clip, run of 32-frame tiles) items.
 //   * snip-edges frames of 400 samples, hop 160; per frame: remove DC, pre-emphasis 0.97, Povey
 //     window, zero-pad to 512 (all fused into the load stage; the x * 2^15 scaling is folded into
 //     the mel bank as 2^30).
@@ -32,9 +32,9 @@
 namespace sttfe {
 
 namespace kaldi {
-constexpr int kThreads = 512;
-constexpr int kWaves = 8;
-constexpr int kTileFrames = 64;            // 8 waves x 8 frames = 4 MFMA frame tiles
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int kTileFrames = 32;            // 4 waves x 8 frames = 2 MFMA frame tiles
 constexpr int kFramesPerWave = 8;
 constexpr int kHop = 160;
 constexpr int kFrame = 400;
@@ -47,9 +47,10 @@ static_assert((kSlabFloats - kFramesPerWave * kPStride) % 32 == 0, "panel rows k
 constexpr int kWinOff = kWaves * kSlabFloats;          // float offsets of the tables inside the LDS array
 constexpr int kTwOff = kWinOff + 400;
 constexpr int kAfragOff = kTwOff + 1024;
-constexpr int kMaxAfragFloats = 4992;      // 78 k-steps x 64 lanes (80 mels need 76)
+constexpr int kMaxAfragFloats = 0;         // the mel weights are read from global memory (L1 / L2 resident)
 constexpr int kDescOff = kAfragOff + kMaxAfragFloats;  // per wave: 8 x {kstart, nsteps, aoff, mt | ft << 8}, then the unit counts
-constexpr int kLdsFloats = kDescOff + kWaves * kMaxUnitsPerWave * 4 + kWaves;     // ~161 KB: one workgroup per CU
+constexpr int kLdsFloats = kDescOff + kWaves * kMaxUnitsPerWave * 4 + kWaves;     // 74 KB: two workgroups per CU
+constexpr int kUnitsCap = 4;               // units one wave owns: ceil(8 mel tiles x 2 frame tiles / 4 waves) at most
 constexpr float kMelFloor = 1.1920928955078125e-07f;
 }  // namespace kaldi
 
@@ -68,29 +69,32 @@ __device__ __forceinline__ int kaldi_num_frames(int n, int max_frames, int t_max
     return t > t_max ? t_max : t;
 }
 
-// One 512-thread workgroup (8 waves, <= 256 VGPRs, ~161 KB LDS -> one per CU) walks a run of consecutive
-// 64-frame tiles of one clip.  Window, twiddles, the banded mel weights (MFMA B-operand order) and the
-// per-wave unit plan are staged in LDS once per run; the CMVN sums of the run are kept in registers
-// (float64) and reach memory with one atomic per mel bin and wave at the end of the run.
+// Persistent 256-thread workgroups (4 waves, <= 256 VGPRs, 74 KB LDS -> two per CU, grid = 2 x CUs).  A workgroup
+// stages window, twiddles and the per-wave unit plan in LDS once and then takes work items -- (clip, run of
+// consecutive 32-frame tiles), clip-major -- from a ticket counter in the workspace: ragged batches (config 2:
+// 2-10 s clips) are spread evenly over the chip instead of the longest clip setting the time (0.141 -> 0.114 ms).
+// The banded mel weights (MFMA B-operand order) are read from global memory (L1 / L2 resident); the CMVN sums of
+// an item are kept in registers (float64) and reach memory with one atomic per mel bin and wave at the end of the
+// item.  The loop ends after at most n_items tickets; all threads of a workgroup take the same path.
+// (Requesting the next item's ticket, length and first PCM tile an item ahead, as the Whisper kernel does, needs
+// one of the two PCM passes to be fetched late for register room and was measured slower: 0.127 ms.)
 __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     const float* __restrict__ pcm, const int64_t* __restrict__ offsets,
     const int32_t* __restrict__ lengths, int n_mels, int t_max, int max_frames,
     const KaldiTablesHeader* __restrict__ tab, float* __restrict__ out, double* __restrict__ stats,
-    int tiles_per_block) {
+    int tiles_per_block, int n_runs, int n_items, unsigned* __restrict__ ticket) {
     using namespace kaldi;
     __shared__ __attribute__((aligned(16))) float smem[kLdsFloats];
+    __shared__ unsigned s_next[2];
 
-    const int clip = blockIdx.y;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float* __restrict__ x = pcm + offsets[clip];
-    const int n_valid = lengths[clip];
-    const int T = kaldi_num_frames(n_valid, max_frames, t_max);
-    const int n_tiles = (T + kTileFrames - 1) / kTileFrames;
-    const int tile_begin = blockIdx.x * tiles_per_block;
-    const int tile_end = min(tile_begin + tiles_per_block, n_tiles);
-    if (tile_begin >= tile_end) return;
+    int item = blockIdx.x;
+    if (item >= n_items) return;
+    // per-item state (set at the top of the item loop; the lambdas below read it by reference)
+    const float* __restrict__ x = pcm;
+    int n_valid = 0;
 
     // stage-1 lane roles: half-wave h = pair within the round, n2 = column
     const int h = lane >> 5, n2 = lane & 31;
@@ -120,8 +124,6 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
         }
     };
     float raw0[18], prv0[18], raw1[18], prv1[18];
-    load_pass(tile_begin * kTileFrames, 0, raw0, prv0);
-    load_pass(tile_begin * kTileFrames, 1, raw1, prv1);
 
     // The pad cells of the panel rows are read by zero-weight MFMA steps and must be finite.  A panel row aliases
     // the wave's exchange slab, whose cells are all rewritten with finite values by every tile except the pad
@@ -137,8 +139,7 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     for (int i = tid; i < 1024; i += kThreads) smem[kTwOff + i] = tab->twiddle[i];
     {
         const float* __restrict__ afrag_g = reinterpret_cast<const float*>(tab + 1);
-        const int na = min(tab->afrag_floats, kMaxAfragFloats);
-        for (int i = tid; i < na; i += kThreads) smem[kAfragOff + i] = afrag_g[i];
+        (void)afrag_g;
         int* desc = reinterpret_cast<int*>(smem + kDescOff);
         if (tid < kWaves * kMaxUnitsPerWave)
             reinterpret_cast<int4k*>(desc)[tid] = reinterpret_cast<const int4k*>(&tab->plan.desc[0][0][0])[tid];
@@ -146,16 +147,14 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     }
     __syncthreads();
 
-    const float* wfrag = smem + kAfragOff;
+    const float* __restrict__ wfrag = reinterpret_cast<const float*>(tab + 1);
     const int4k* desc = reinterpret_cast<const int4k*>(smem + kDescOff) + wave * kMaxUnitsPerWave;
-    const int nu = __builtin_amdgcn_readfirstlane(
-        reinterpret_cast<const int*>(smem + kDescOff)[4 * kWaves * kMaxUnitsPerWave + wave]);
+    const int nu = min(kUnitsCap, __builtin_amdgcn_readfirstlane(
+        reinterpret_cast<const int*>(smem + kDescOff)[4 * kWaves * kMaxUnitsPerWave + wave]));
     const cf* tw_tab = reinterpret_cast<const cf*>(smem + kTwOff);
     const float* win = smem + kWinOff;
     float* my_rows = smem + wave * kSlabFloats;
     cf* slab_w = reinterpret_cast<cf*>(my_rows);
-    float* __restrict__ out_clip = out + (size_t)clip * t_max * n_mels;
-    double* __restrict__ st = stats + (size_t)clip * 2 * n_mels;
 
     // stage-2 lane roles: q = pair, k1 = row
     const int q = lane >> 4, k1 = lane & 15;
@@ -165,12 +164,33 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
         const int fl = ft * 16 + (lane & 15), fw = fl / kFramesPerWave;
         return fw * kSlabFloats + (fl - fw * kFramesPerWave) * kPStride + (lane >> 4);
     };
-    const int prow0 = p_row(0), prow1 = p_row(1), prow2 = p_row(2), prow3 = p_row(3);
+    const int prow0 = p_row(0), prow1 = p_row(1);
 
-    // CMVN sums of this wave's units over the run (a wave owns the same (mel tile, frame tile) units in every tile)
-    double s1[kMaxUnitsPerWave], s2[kMaxUnitsPerWave];
+    unsigned iter = 0;
+    while (item < n_items) {
+    unsigned my_ticket = 0;
+    if (tid == 0) my_ticket = atomicAdd(ticket, 1u);               // the workgroup's next item, needed at the end of this one
+    const int clip = __builtin_amdgcn_readfirstlane(item / n_runs), run = item - clip * n_runs;
+    n_valid = __builtin_amdgcn_readfirstlane(lengths[clip]);
+    {
+        const int64_t o = offsets[clip];
+        x = pcm + (((int64_t)__builtin_amdgcn_readfirstlane((int)(o >> 32)) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)o));
+    }
+    const int T = kaldi_num_frames(n_valid, max_frames, t_max);
+    const int n_tiles = (T + kTileFrames - 1) / kTileFrames;
+    const int tile_begin = run * tiles_per_block;
+    const int tile_end = min(tile_begin + tiles_per_block, n_tiles);
+    if (tile_begin < tile_end) {
+    float* __restrict__ out_clip = out + (size_t)clip * t_max * n_mels;
+    double* __restrict__ st = stats + (size_t)clip * 2 * n_mels;
+    load_pass(tile_begin * kTileFrames, 0, raw0, prv0);
+    load_pass(tile_begin * kTileFrames, 1, raw1, prv1);
+
+    // CMVN sums of this wave's units over the item (a wave owns the same (mel tile, frame tile) units in every tile)
+    double s1[kUnitsCap], s2[kUnitsCap];
 #pragma unroll
-    for (int u = 0; u < kMaxUnitsPerWave; ++u) s1[u] = s2[u] = 0.0;
+    for (int u = 0; u < kUnitsCap; ++u) s1[u] = s2[u] = 0.0;
 
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const int t0 = tile * kTileFrames;
@@ -264,7 +284,7 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
         // ---------------- banded mel projection (frames x mels) + ln + CMVN statistics -----------
         int4k d = desc[0];                                          // {kstart, nsteps, aoff, mt | ft << 8}
 #pragma unroll
-        for (int u = 0; u < kMaxUnitsPerWave; ++u) {
+        for (int u = 0; u < kUnitsCap; ++u) {
             if (u < nu) {
                 const int ks = __builtin_amdgcn_readfirstlane(d.x);
                 const int ns = __builtin_amdgcn_readfirstlane(d.y);     // multiple of 4 (tables.cpp)
@@ -273,7 +293,7 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
                 d = desc[u + 1 < kMaxUnitsPerWave ? u + 1 : u];
                 const int mt = code & 0xff, ft = code >> 8;
                 const float* w_ptr = wfrag + ao + lane;
-                const float* p_ptr = smem + (ft == 0 ? prow0 : ft == 1 ? prow1 : ft == 2 ? prow2 : prow3) + ks;
+                const float* p_ptr = smem + (ft == 0 ? prow0 : prow1) + ks;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
                 float pv[4], wq[4];
 #pragma unroll
@@ -324,7 +344,7 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
 
     // ---------------- CMVN sums of the run: lanes l, l+16, l+32, l+48 share a mel bin ---------------
 #pragma unroll
-    for (int u = 0; u < kMaxUnitsPerWave; ++u) {
+    for (int u = 0; u < kUnitsCap; ++u) {
         if (u < nu) {
             double a = s1[u], b2 = s2[u];
             a += __shfl_xor(a, 16, 64);
@@ -339,6 +359,14 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
             }
         }
     }
+    }   // item has tiles
+    // hand-over of the next item through one of two alternating LDS slots (a slot is rewritten only after the
+    // barrier of the following item, which every thread reaches after this read)
+    if (tid == 0) s_next[iter & 1u] = my_ticket + gridDim.x;
+    __syncthreads();
+    item = (int)min(s_next[iter & 1u], (unsigned)n_items);
+    ++iter;
+    }   // items
 }
 
 // out[b][t][m] <- (x - mean_m) / std_m for t < T_b, 0 for padded rows; masks <- 0; attention mask.
@@ -399,7 +427,8 @@ using namespace sttfe;
 
 extern "C" int sttfe_kaldi_workspace_bytes(int batch, int n_mels, size_t* bytes) {
     if (batch < 0 || n_mels < 1 || n_mels > 128 || !bytes) return STTFE_E_INVALID_ARG;
-    *bytes = ((size_t)batch * 2 * n_mels * sizeof(double) + 255) / 256 * 256;
+    // per-clip per-bin float64 sums, then the work-item ticket counter
+    *bytes = ((size_t)batch * 2 * n_mels * sizeof(double) + 255) / 256 * 256 + 256;
     return STTFE_OK;
 }
 
@@ -422,20 +451,29 @@ extern "C" int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, 
     if (hip_failed(hipMemsetAsync(stats, 0, need, stream), "hipMemsetAsync(cmvn stats)")) return STTFE_E_LAUNCH;
     const auto* tab = reinterpret_cast<const KaldiTablesHeader*>(dev_tables);
     const int n_tiles = (t_max + kaldi::kTileFrames - 1) / kaldi::kTileFrames;
-    // one workgroup per CU: runs as long as possible while the batch still gives >= 2 rounds of workgroups
-    static const int runs_env = [] {
-        const char* e = getenv("STTFE_KALDI_RUNS");                // tuning knob: runs per clip (0 / unset = automatic)
+    // persistent workgroups, two per CU; short runs (2 tiles = 64 frames) keep ragged batches balanced
+    static const int tpb_env = [] {
+        const char* e = getenv("STTFE_KALDI_TILES_PER_ITEM");      // tuning knob (0 / unset = 2)
         const int v = e ? atoi(e) : 0;
-        return v < 0 ? 0 : v;
+        return v < 1 ? 2 : v;
     }();
-    int runs = runs_env ? runs_env : (512 + batch - 1) / batch;
-    runs = runs < 1 ? 1 : (runs > n_tiles ? n_tiles : runs);
-    const int tiles_per_block = (n_tiles + runs - 1) / runs;
-    const int bx = (n_tiles + tiles_per_block - 1) / tiles_per_block;
+    const int tiles_per_block = tpb_env;
+    const int n_runs = (n_tiles + tiles_per_block - 1) / tiles_per_block;
+    if ((long)n_runs * batch > 0x3fffffffL) return STTFE_E_UNSUPPORTED;
+    const int n_items = n_runs * batch;
+    static const int resident = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            cus = 256;
+        return 2 * cus;
+    }();
+    const int grid = n_items < resident ? n_items : resident;
+    unsigned* ticket = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + need - 256);
     {
         ScopedTiming t(kTimeKaldiFbank, stream);
-        hipLaunchKernelGGL(kaldi_fbank_kernel, dim3(bx, batch), dim3(kaldi::kThreads), 0, stream, pcm, offsets,
-                           lengths, n_mels, t_max, max_frames, tab, out, stats, tiles_per_block);
+        hipLaunchKernelGGL(kaldi_fbank_kernel, dim3(grid), dim3(kaldi::kThreads), 0, stream, pcm, offsets,
+                           lengths, n_mels, t_max, max_frames, tab, out, stats, tiles_per_block, n_runs, n_items, ticket);
     }
     {
         ScopedTiming t(kTimeKaldiCmvn, stream);

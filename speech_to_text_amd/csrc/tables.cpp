@@ -220,7 +220,7 @@ static int kaldi_tables(int n_mels, std::vector<unsigned char>& blob) {
     std::memset(&h, 0, sizeof(h));
     // 2^28 = (2^15)^2 [the x * 2**15 of HF speech_to_text.py:112 applied to the power spectrum] * 1/4
     // [two-real-frames separation]; a power of two, so folding it into the bank is exact.
-    build_mel_plan(dense, n_mels, 257, 268435456.0f, 8, 4, 4, 0, h.plan, afrag);   // 8 waves x 4 frame tiles, bands padded to 4 steps
+    build_mel_plan(dense, n_mels, 257, 268435456.0f, 4, 2, 4, 0, h.plan, afrag);   // 8 waves x 4 frame tiles, bands padded to 4 steps
     h.magic = kKaldiMagic;
     h.n_mels = n_mels;
     h.afrag_floats = (int32_t)afrag.size();
