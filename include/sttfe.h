@@ -87,6 +87,8 @@ int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, const int32_t
 int sttfe_kaldi_tables_bytes(int n_mels, size_t* bytes);
 int sttfe_kaldi_tables_build(int n_mels, void* host_blob, size_t bytes);
 int sttfe_kaldi_mel_bank(int n_mels, float* host_dense /* [n_mels][257] */);
+/* workspace = per-clip per-bin float64 sums for CMVN + the kernel's work-item ticket counter; the entry
+ * point zeroes it itself on `stream`. */
 int sttfe_kaldi_workspace_bytes(int batch, int n_mels, size_t* bytes);
 
 /*
