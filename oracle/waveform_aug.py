@@ -12,7 +12,7 @@ Draw order per clip (every gate consumes one ``random.random()`` whether it pass
 
     noise  gate -> torch.randn_like(audio)                    (global torch CPU generator)
     speed  gate -> torch.randint(len(factors), ())            factors = np.linspace(lo, hi, steps)
-    pitch  gate -> random.randint(lo, hi)                     (the shift itself is not restated: rank 4 of 8(f))
+    pitch  gate -> random.randint(lo, hi)                     (semitones; applied by oracle/pitch_shift.py)
     volume gate -> random.uniform(lo_db, hi_db); gain = 10 ** (db / 20)
     fade   gate -> fade samples = int(fade_duration * sample_rate)
 """
@@ -26,6 +26,7 @@ from typing import Any, Optional
 import numpy as np
 import torch
 
+from .pitch_shift import pitch_shift as _pitch_shift
 from .resample import resample as _resample
 
 
@@ -70,8 +71,10 @@ def speed_rates(factor: float, sample_rate: int = 16000):
     return source // g, target // g
 
 
-def apply_time_domain(x: np.ndarray, d: ClipDraw, sample_rate: int = 16000) -> np.ndarray:
-    """One mono clip (n,) float32 -> augmented clip (pitch shift excepted), torch CPU float32 arithmetic."""
+def apply_time_domain(x: np.ndarray, d: ClipDraw, sample_rate: int = 16000,
+                      pitch_mode: Optional[str] = "as_constructed") -> np.ndarray:
+    """One mono clip (n,) float32 -> augmented clip, torch CPU float32 arithmetic.  ``pitch_mode`` None skips the
+    pitch shift (its draw stays consumed)."""
     t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).reshape(1, -1)
     if d.noise_factor is not None:
         t = t + d.noise * d.noise_factor                                      # src/data.py:156-157
@@ -79,6 +82,8 @@ def apply_time_domain(x: np.ndarray, d: ClipDraw, sample_rate: int = 16000) -> n
         src, dst = speed_rates(d.speed_factor, sample_rate)
         if src != dst:
             t = torch.from_numpy(_resample(t.numpy().reshape(-1), src, dst)).reshape(1, -1)
+    if d.pitch_steps is not None and pitch_mode is not None:                  # src/data.py:164-167
+        t = torch.from_numpy(_pitch_shift(t.numpy().reshape(-1), int(d.pitch_steps), sample_rate, pitch_mode)).reshape(1, -1)
     if d.gain is not None:
         t = torch.clamp(t * d.gain, -1, 1)                                    # torchaudio Vol, gain_type="amplitude"
     if d.fade_samples is not None:

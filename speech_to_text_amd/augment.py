@@ -84,6 +84,9 @@ class SpecAugmentSampler:
 
 # ------------------------------------------------------------------ waveform-domain augmentations
 AUG_NOISE, AUG_GAIN, AUG_FADE = 1, 2, 4          # STTFE_AUG_*
+PITCH_NONE = -2 ** 31                            # STTFE_PITCH_NONE
+PITCH_MODES = {"as_constructed": 0, "functional": 1, "off": None}      # STTFE_PITCH_AS_CONSTRUCTED / _FUNCTIONAL
+PITCH_MIN_SAMPLES = 257                          # torch.stft's reflect padding needs n > n_fft / 2
 
 
 @dataclass
@@ -92,7 +95,7 @@ class WaveformDraw:
     noise_factor: Optional[float] = None
     noise: Optional[torch.Tensor] = None         # (n,) host standard-normal samples when noise_source == "host"
     speed_factor: Optional[float] = None
-    pitch_steps: Optional[int] = None            # drawn (keeps the RNG streams aligned) but not applied
+    pitch_steps: Optional[int] = None            # semitones, random.randint(*pitch_shift_range)
     gain: Optional[float] = None
     fade_samples: Optional[int] = None
 
@@ -108,14 +111,22 @@ class WaveformAugmentSampler:
     ``noise_source="host"`` draws the noise itself from the torch CPU generator, exactly like the reference
     (bit parity; n floats per noisy clip cross PCIe); ``"device"`` leaves it to the GPU generator (same
     distribution, different stream) -- the default, since the noise is 4 bytes per sample.
-    Pitch shift is not built: its draws are consumed and a warning is logged once.
+    ``pitch_mode``: ``"as_constructed"`` (default) applies what the reference's ``PitchShift(sample_rate, n_steps=0)``
+    object computes once its ``n_steps`` attribute is overwritten -- the phase-vocoder stretch without the
+    resample, whose ratio the transform fixed at construction -- ``"functional"`` applies
+    ``torchaudio.functional.pitch_shift`` with the drawn steps, ``"off"`` consumes the draws and leaves the clip
+    alone (``sttfe_pitch_shift``, include/sttfe.h).
     """
 
-    def __init__(self, config: Any = None, sample_rate: int = 16000, noise_source: str = "device", **overrides):
+    def __init__(self, config: Any = None, sample_rate: int = 16000, noise_source: str = "device",
+                 pitch_mode: str = "as_constructed", **overrides):
         get = lambda k, d: overrides.get(k, getattr(config, k, d) if config is not None else d)
         if noise_source not in ("host", "device"):
             raise ValueError("noise_source must be 'host' or 'device'")
+        if pitch_mode not in PITCH_MODES:
+            raise ValueError("pitch_mode must be one of %s" % (sorted(PITCH_MODES),))
         self.noise_source = noise_source
+        self.pitch_mode = pitch_mode
         self.sample_rate = int(sample_rate)
         self.add_noise = bool(get("add_noise", True))
         self.noise_probability = float(get("noise_probability", 0.3))
@@ -133,7 +144,6 @@ class WaveformAugmentSampler:
         self.fade_inout = bool(get("fade_inout", True))
         self.fade_probability = float(get("fade_probability", 0.2))
         self.fade_duration = float(get("fade_duration", 0.1))
-        self._warned_pitch = False
 
     def draw_clip(self, n_samples: int) -> WaveformDraw:
         d = WaveformDraw()
@@ -145,9 +155,6 @@ class WaveformAugmentSampler:
             d.speed_factor = float(self.speed_factors[int(torch.randint(len(self.speed_factors), ()))])
         if self.pitch_shift and random.random() < self.pitch_probability:
             d.pitch_steps = random.randint(*self.pitch_shift_range)
-            if not self._warned_pitch:
-                logger.warning("pitch shift is not available in the GPU front-end: draw consumed, clip left unshifted")
-                self._warned_pitch = True
         if self.volume_perturbation and random.random() < self.volume_probability:
             d.gain = 10 ** (random.uniform(*self.volume_range_db) / 20.0)
         if self.fade_inout and random.random() < self.fade_probability:
@@ -175,7 +182,7 @@ def _fbits(v: float) -> int:
 class GpuWaveformAugmenter:
     """Applies a batch of ``WaveformDraw`` to packed PCM on the GPU (``sttfe_waveform_augment`` + resampler).
 
-    Order as in the reference: noise -> speed -> (pitch: skipped) -> volume -> fade.
+    Order as in the reference: noise -> speed -> pitch -> volume -> fade.
     """
 
     def __init__(self, sampler: WaveformAugmentSampler):
@@ -189,6 +196,39 @@ class GpuWaveformAugmenter:
             p = ResamplePlan(src, dst)
             self._plans[(src, dst)] = p
         return p
+
+    def pitch_shift(self, packed, steps: Sequence[Optional[int]], mode: Optional[str] = None):
+        """In place: clip b of ``packed`` shifted by ``steps[b]`` semitones (None = untouched) with
+        ``sttfe_pitch_shift``.  Raises RuntimeError for an active clip of fewer than 257 samples (torch.stft
+        raises there in the reference)."""
+        from . import _lib
+        mode_id = PITCH_MODES[mode or self.sampler.pitch_mode]
+        B = len(steps)
+        if mode_id is None or B == 0 or all(s is None for s in steps):
+            return packed
+        L = _lib.lib()
+        lens = np.asarray(packed.host_lengths, dtype=np.int32)
+        if len(lens) != B:
+            raise ValueError("one pitch step entry per clip is required")
+        n_steps = np.asarray([PITCH_NONE if s is None else int(s) for s in steps], dtype=np.int64).astype(np.int32)
+        short = [b for b in range(B) if steps[b] is not None and lens[b] < PITCH_MIN_SAMPLES]
+        if short:
+            raise RuntimeError("pitch shift needs clips of at least %d samples (clips %s)" % (PITCH_MIN_SAMPLES, short))
+        layout = np.zeros((B, 8), dtype=np.int64)
+        ws_bytes = ctypes.c_size_t()
+        _lib.check(L.sttfe_pitch_shift_plan(lens.ctypes.data_as(ctypes.c_void_p), n_steps.ctypes.data_as(ctypes.c_void_p),
+                                            B, int(packed.sample_rate), mode_id,
+                                            layout.ctypes.data_as(ctypes.c_void_p), ctypes.byref(ws_bytes)),
+                   "sttfe_pitch_shift_plan")
+        device = packed.pcm.device
+        ws = torch.empty(max(ws_bytes.value, 16), dtype=torch.uint8, device=device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        with torch.cuda.device(device):
+            _lib.check(L.sttfe_pitch_shift(_lib.ptr(packed.pcm), _lib.ptr(packed.offsets), _lib.ptr(packed.lengths), B,
+                                           layout.ctypes.data_as(ctypes.c_void_p), mode_id, _lib.ptr(ws), ws.numel(),
+                                           stream), "sttfe_pitch_shift")
+        ws.record_stream(torch.cuda.current_stream(device))
+        return packed
 
     def apply(self, packed, draws: Sequence[WaveformDraw]):
         """``packed``: preprocess.PackedAudio (mono, device).  Returns a PackedAudio (new buffers when any clip's
@@ -250,9 +290,16 @@ class GpuWaveformAugmenter:
                                                     _lib.ptr(noise_off) if noise_off is not None else None,
                                                     int(stages), stream), "sttfe_waveform_augment")
 
-        if not speed_groups:
+        pitch_steps = [d.pitch_steps for d in draws]
+        any_pitch = self.sampler.pitch_mode != "off" and any(s is not None for s in pitch_steps)
+        if not speed_groups and not any_pitch:
             run(packed, AUG_NOISE | AUG_GAIN | AUG_FADE)
             out = packed
+        elif not speed_groups:
+            if any_noise:
+                run(packed, AUG_NOISE)
+            out = self.pitch_shift(packed, pitch_steps)
+            run(out, AUG_GAIN | AUG_FADE)
         else:
             if any_noise:
                 run(packed, AUG_NOISE)
@@ -286,6 +333,8 @@ class GpuWaveformAugmenter:
                                                      _lib.ptr(ws), ws.numel(), stream), "sttfe_resample_peak")
                 out_lengths[sel] = o_len
             out = PackedAudio(pcm_out, out_offsets, out_lengths, new_lens, packed.sample_rate, keep)
+            if any_pitch:
+                self.pitch_shift(out, pitch_steps)
             run(out, AUG_GAIN | AUG_FADE)
         for b, d in enumerate(draws):
             if d.fade_samples is not None and d.fade_samples > out.host_lengths[b]:

@@ -20,7 +20,7 @@ class AugmentationConfig:
     speed_probability: float = 0.3           # :22
     speed_factor_range: tuple = (0.9, 1.1)   # :23
     speed_num_steps: int = 3                 # :24
-    pitch_shift: bool = True                 # :26 (draws consumed, shift not applied on the GPU path)
+    pitch_shift: bool = True                 # :26 (sttfe_pitch_shift; GpuFrontEnd(pitch_mode=...))
     pitch_probability: float = 0.3           # :27
     pitch_shift_range: tuple = (-2, 2)       # :28
     volume_perturbation: bool = True         # :30

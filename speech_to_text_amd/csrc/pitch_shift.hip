@@ -1,0 +1,440 @@
+// Pitch shift of the reference's waveform augmentation, batched and in place on packed PCM.
+//
+// Reference: src/data.py:133-136 builds torchaudio.transforms.PitchShift(sample_rate, n_steps=0) and
+// src/data.py:163-167 overwrites its n_steps with random.randint(-2, 2) per clip before calling it.  torchaudio
+// 2.5.1 computes (functional.pitch_shift): rate = 2^(-n_steps/12);
+//   S = stft(x, 512, hop 128, periodic hann, center / reflect)                    -> pv_stft_kernel
+//   S' = phase_vocoder(S, rate, linspace(0, pi*128, 257))                         -> pv_stretch_kernel
+//   y = istft(S', length = round(n / rate))                                       -> pv_frames_kernel + pv_overlap_add_kernel
+//   y = resample(y, int(sr / rate) -> sr), sinc_interp_hann, width 6, rolloff .99 -> pv_resample_kernel
+//   crop / zero-pad y to n samples                                                -> fused into the last kernel
+// STTFE_PITCH_AS_CONSTRUCTED is what the reference's transform object does: its orig_freq is fixed in the
+// constructor, where n_steps is 0, so the resample is skipped and the clip comes back time-stretched and cropped /
+// padded; STTFE_PITCH_FUNCTIONAL is the full functional.pitch_shift with the drawn n_steps.
+// Parity unpinned (torchaudio absent): restated from the algorithm text; oracle/pitch_shift.py runs the same
+// steps on the real torch.stft / torch.istft.
+//
+// Data: per active clip the workspace holds S [T][257] complex, S' [T'][257] complex, the windowed inverse
+// frames [T'][512] and (functional mode) the stretched waveform; `layout` rows (built on the host by
+// sttfe_pitch_shift_plan from the host's copy of the lengths) carry the offsets, so no kernel derives a size
+// from device data: a clip whose device length differs from the planned one is left untouched.
+// 512-point transforms: one wave per pair of real frames (z = x1 + i x2), 8 points per lane, three radix-8
+// Stockham passes through a 4 KB LDS panel, twiddles and window from LDS tables computed in float64.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cmath>
+#include <cstring>
+
+#include "../../include/sttfe.h"
+#include "fft_core.h"
+#include "timing.h"
+
+// torch rounds every product and sum separately (see waveform_aug.hip)
+#pragma clang fp contract(off)
+
+namespace sttfe {
+
+constexpr int kPvN = 512, kPvHop = 128, kPvBins = 257, kPvPad = 256;
+constexpr int kPvWaves = 4;
+constexpr int kLayoutWords = 8;        // int64 per clip: spec, stretch, frames, wave offsets (floats); T | T'<<32;
+                                       // n | len_stretch<<32; rate (double bits); orig | new<<32 (reduced rates)
+
+struct PvClip {
+    int64_t spec, stretch, frames, wave;
+    int T, T_out, n, len_stretch;
+    double rate;
+    int orig, neu;
+};
+
+__device__ __forceinline__ PvClip load_clip(const int64_t* __restrict__ layout, int clip) {
+    const int64_t* r = layout + (int64_t)clip * kLayoutWords;
+    PvClip c;
+    c.spec = r[0];
+    c.stretch = r[1];
+    c.frames = r[2];
+    c.wave = r[3];
+    c.T = (int)(r[4] & 0xffffffff);
+    c.T_out = (int)(r[4] >> 32);
+    c.n = (int)(r[5] & 0xffffffff);
+    c.len_stretch = (int)(r[5] >> 32);
+    c.rate = __longlong_as_double(r[6]);
+    c.orig = (int)(r[7] & 0xffffffff);
+    c.neu = (int)(r[7] >> 32);
+    return c;
+}
+
+__device__ __forceinline__ void fill_tables(cf* tw, float* win) {
+    for (int i = threadIdx.x; i < kPvN; i += blockDim.x) {
+        double s, c;
+        sincospi(-2.0 * (double)i / kPvN, &s, &c);
+        tw[i] = cf{(float)c, (float)s};
+        win[i] = (float)(0.5 - 0.5 * cospi(2.0 * (double)i / kPvN));       // torch.hann_window(512), periodic
+    }
+}
+
+// Forward 512-point DFT of the panel (natural order in and out).  Every wave of the workgroup must call it the
+// same number of times (workgroup barriers inside).
+__device__ __forceinline__ void fft512_panel(cf* __restrict__ panel, const cf* __restrict__ tw, int lane) {
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        const int ns = pass == 0 ? 1 : (pass == 1 ? 8 : 64);
+        const int k = lane & (ns - 1);
+        const int tw_step = (kPvN / 8) / ns * k;                           // r * k * 512 / (8 ns)
+        cf v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = panel[lane + 64 * r];
+        if (pass > 0) {
+#pragma unroll
+            for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw[r * tw_step]);
+        }
+        dft8(v);
+        const int j0 = (lane - k) * 8 + k;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) panel[j0 + r * ns] = v[r];
+        __syncthreads();
+    }
+}
+
+// ---- S = stft(x): grid (gx, batch), 4 waves, one pair of frames per wave and trip
+__global__ __launch_bounds__(64 * kPvWaves) void pv_stft_kernel(const float* __restrict__ pcm,
+                                                                const int64_t* __restrict__ offsets,
+                                                                const int32_t* __restrict__ lengths,
+                                                                const int64_t* __restrict__ layout,
+                                                                float* __restrict__ ws) {
+    __shared__ cf s_tw[kPvN];
+    __shared__ float s_win[kPvN];
+    __shared__ cf s_panel[kPvWaves][kPvN];
+    const int clip = blockIdx.y;
+    const PvClip c = load_clip(layout, clip);
+    if (c.T <= 0 || lengths[clip] != c.n) return;                          // uniform over the workgroup
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    fill_tables(s_tw, s_win);
+    __syncthreads();
+    const float* __restrict__ x = pcm + offsets[clip];
+    cf* __restrict__ spec = reinterpret_cast<cf*>(ws + c.spec);
+    cf* panel = s_panel[wave];
+    const int n_pairs = (c.T + 1) / 2;
+    const int stride = gridDim.x * kPvWaves;
+    const int trips = (n_pairs + stride - 1) / stride;
+    for (int it = 0; it < trips; ++it) {
+        const int pair = it * stride + blockIdx.x * kPvWaves + wave;
+        const int t0 = 2 * pair, t1 = t0 + 1;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = lane + 64 * r;
+            auto sample = [&](int t) {
+                if (t >= c.T) return 0.0f;
+                int idx = t * kPvHop + i - kPvPad;
+                if (idx < 0) idx = -idx;
+                if (idx >= c.n) idx = 2 * (c.n - 1) - idx;
+                return x[idx] * s_win[i];
+            };
+            panel[i] = cf{sample(t0), sample(t1)};
+        }
+        __syncthreads();
+        fft512_panel(panel, s_tw, lane);
+        // X1[k] = (Z[k] + conj Z[N-k]) / 2, X2[k] = (Z[k] - conj Z[N-k]) / 2i
+        for (int k = lane; k < kPvBins; k += 64) {
+            const cf a = panel[k], b = panel[(kPvN - k) & (kPvN - 1)];
+            if (t0 < c.T) spec[(int64_t)t0 * kPvBins + k] = cf{0.5f * (a.x + b.x), 0.5f * (a.y - b.y)};
+            if (t1 < c.T) spec[(int64_t)t1 * kPvBins + k] = cf{0.5f * (a.y + b.y), 0.5f * (b.x - a.x)};
+        }
+        __syncthreads();
+    }
+}
+
+// ---- S' = phase_vocoder(S): one thread per (clip, bin), sequential in time (the phase is a running sum)
+__global__ __launch_bounds__(64) void pv_stretch_kernel(const int32_t* __restrict__ lengths,
+                                                        const int64_t* __restrict__ layout, float* __restrict__ ws) {
+    const int clip = blockIdx.y;
+    const PvClip c = load_clip(layout, clip);
+    if (c.T <= 0 || lengths[clip] != c.n) return;
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= kPvBins) return;
+    const cf* __restrict__ spec = reinterpret_cast<const cf*>(ws + c.spec);
+    cf* __restrict__ out = reinterpret_cast<cf*>(ws + c.stretch);
+    if (c.rate == 1.0) {                                                   // phase_vocoder returns its input
+        for (int t = 0; t < c.T_out; ++t) out[(int64_t)t * kPvBins + k] = spec[(int64_t)t * kPvBins + k];
+        return;
+    }
+    // torch.linspace(0, pi * hop, 257)[k], float32
+    const float end = (float)(M_PI * kPvHop);
+    const float step = end / (float)(kPvBins - 1);
+    const float adv = k < kPvBins / 2 ? step * (float)k : end - step * (float)(kPvBins - 1 - k);
+    const float two_pi = (float)(2.0 * M_PI);
+    auto at = [&](int t) { return t < c.T ? spec[(int64_t)t * kPvBins + k] : cf{0.f, 0.f}; };
+    const cf first = at(0);
+    double acc = 0.0;                                                      // torch.cumsum accumulates float in double on the CPU
+    float pending = atan2f(first.y, first.x);
+    for (int j = 0; j < c.T_out; ++j) {
+        const float ts = (float)((double)j * c.rate);
+        const int i0 = (int)ts;
+        const float alpha = ts - floorf(ts);
+        const cf lo = at(i0), hi = at(i0 + 1);
+        const float n0 = hypotf(lo.x, lo.y), n1 = hypotf(hi.x, hi.y);
+        float ph = atan2f(hi.y, hi.x) - atan2f(lo.y, lo.x) - adv;
+        ph = ph - two_pi * rintf(ph / two_pi);
+        ph = ph + adv;
+        acc += (double)pending;
+        pending = ph;
+        const float mag = alpha * n1 + (1.0f - alpha) * n0;
+        const float a = (float)acc;
+        out[(int64_t)j * kPvBins + k] = cf{mag * cosf(a), mag * sinf(a)};
+    }
+}
+
+// ---- windowed inverse frames: irfft(S'[t]) * window, two frames per 512-point transform
+__global__ __launch_bounds__(64 * kPvWaves) void pv_frames_kernel(const int32_t* __restrict__ lengths,
+                                                                  const int64_t* __restrict__ layout,
+                                                                  float* __restrict__ ws) {
+    __shared__ cf s_tw[kPvN];
+    __shared__ float s_win[kPvN];
+    __shared__ cf s_panel[kPvWaves][kPvN];
+    const int clip = blockIdx.y;
+    const PvClip c = load_clip(layout, clip);
+    if (c.T <= 0 || lengths[clip] != c.n) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    fill_tables(s_tw, s_win);
+    __syncthreads();
+    const cf* __restrict__ S = reinterpret_cast<const cf*>(ws + c.stretch);
+    float* __restrict__ frames = ws + c.frames;
+    cf* panel = s_panel[wave];
+    const int n_pairs = (c.T_out + 1) / 2;
+    const int stride = gridDim.x * kPvWaves;
+    const int trips = (n_pairs + stride - 1) / stride;
+    for (int it = 0; it < trips; ++it) {
+        const int pair = it * stride + blockIdx.x * kPvWaves + wave;
+        const int t0 = 2 * pair, t1 = t0 + 1;
+        // Z = ext(S0) + i ext(S1) with the Hermitian extension; the panel takes conj(Z): ifft(Z) = conj(fft(conj Z)) / N
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = lane + 64 * r;
+            const int m = i <= kPvN / 2 ? i : kPvN - i;
+            const float sgn = i <= kPvN / 2 ? 1.0f : -1.0f;
+            auto bin = [&](int t) {
+                if (t >= c.T_out) return cf{0.f, 0.f};
+                cf v = S[(int64_t)t * kPvBins + m];
+                v.y = (m == 0 || m == kPvN / 2) ? 0.0f : v.y * sgn;      // c2r ignores the imaginary part of DC / Nyquist
+                return v;
+            };
+            const cf a = bin(t0), b = bin(t1);
+            panel[i] = cf{a.x - b.y, -(a.y + b.x)};
+        }
+        __syncthreads();
+        fft512_panel(panel, s_tw, lane);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = lane + 64 * r;
+            const cf v = panel[i];
+            const float w = s_win[i];
+            if (t0 < c.T_out) frames[(int64_t)t0 * kPvN + i] = (v.x * (1.0f / kPvN)) * w;
+            if (t1 < c.T_out) frames[(int64_t)t1 * kPvN + i] = (-v.y * (1.0f / kPvN)) * w;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- overlap-add / window envelope, trimmed by n_fft/2 and cut or zero-padded to `count` samples.
+// as-constructed mode: dst = the clip itself, count = n; functional mode: dst = the wave buffer, count = len_stretch.
+__global__ __launch_bounds__(256) void pv_overlap_add_kernel(float* __restrict__ pcm, const int64_t* __restrict__ offsets,
+                                                             const int32_t* __restrict__ lengths,
+                                                             const int64_t* __restrict__ layout, float* __restrict__ ws,
+                                                             int to_wave) {
+    __shared__ float s_w2[kPvN];
+    const int clip = blockIdx.y;
+    const PvClip c = load_clip(layout, clip);
+    if (c.T <= 0 || lengths[clip] != c.n) return;
+    for (int i = threadIdx.x; i < kPvN; i += blockDim.x) {
+        const float w = (float)(0.5 - 0.5 * cospi(2.0 * (double)i / kPvN));
+        s_w2[i] = w * w;
+    }
+    __syncthreads();
+    const float* __restrict__ frames = ws + c.frames;
+    float* __restrict__ dst = to_wave ? ws + c.wave : pcm + offsets[clip];
+    const int count = to_wave ? c.len_stretch : c.n;
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < count; m += gridDim.x * blockDim.x) {
+        float y = 0.0f;
+        if (m < c.len_stretch) {
+            const int pos = m + kPvPad;
+            const int t_lo = pos >= kPvN ? (pos - kPvN) / kPvHop + 1 : 0;
+            int t_hi = pos / kPvHop;
+            if (t_hi > c.T_out - 1) t_hi = c.T_out - 1;
+            float sum = 0.0f, env = 0.0f;
+            for (int t = t_lo; t <= t_hi; ++t) {
+                sum = sum + frames[(int64_t)t * kPvN + (pos - t * kPvHop)];
+                env = env + s_w2[pos - t * kPvHop];
+            }
+            y = t_hi >= t_lo ? sum / env : 0.0f;
+        }
+        dst[m] = y;
+    }
+}
+
+// ---- functional mode: sinc resample of the stretched waveform, taps evaluated per output sample in float64
+// (torchaudio builds its table in float64 and rounds it to float32), crop / zero-pad to n, into the clip.
+__global__ __launch_bounds__(256) void pv_resample_kernel(float* __restrict__ pcm, const int64_t* __restrict__ offsets,
+                                                          const int32_t* __restrict__ lengths,
+                                                          const int64_t* __restrict__ layout,
+                                                          const float* __restrict__ ws) {
+    const int clip = blockIdx.y;
+    const PvClip c = load_clip(layout, clip);
+    if (c.T <= 0 || lengths[clip] != c.n) return;
+    const float* __restrict__ src = ws + c.wave;
+    float* __restrict__ dst = pcm + offsets[clip];
+    if (c.orig == c.neu) {
+        for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < c.n; j += gridDim.x * blockDim.x)
+            dst[j] = j < c.len_stretch ? src[j] : 0.0f;
+        return;
+    }
+    const double base = (double)(c.orig < c.neu ? c.orig : c.neu) * 0.99;
+    const int width = (int)ceil(6.0 * (double)c.orig / base);
+    const double scale = base / (double)c.orig;
+    const int64_t n_out = ((int64_t)c.neu * c.len_stretch + c.orig - 1) / c.orig;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < c.n; j += gridDim.x * blockDim.x) {
+        float y = 0.0f;
+        if (j < n_out) {
+            const int blk = j / c.neu, ph = j - blk * c.neu;
+            const int centre = (int)(((int64_t)ph * c.orig) / c.neu);     // source offset nearest t = 0
+            const int64_t s0 = (int64_t)blk * c.orig;
+            // torch: arange(0, -new, -1) / new is an int64 / int true division -> a float32 quotient
+            const double phase = (double)__fdiv_rn((float)(-ph), (float)c.neu);
+            for (int d = -width - 1; d <= width + 1; ++d) {
+                const int kk = centre + d;                                 // tap position relative to the block start
+                if (kk < -width || kk >= width + c.orig) continue;        // outside the table row
+                const int64_t s = s0 + kk;
+                if (s < 0 || s >= c.len_stretch) continue;                 // zero padding
+                double t = (phase + (double)kk / (double)c.orig) * base;
+                t = fmin(fmax(t, -6.0), 6.0);
+                const double cw = cos(t * M_PI / 6.0 / 2.0);
+                const double tp = t * M_PI;
+                const double tap = (tp == 0.0 ? 1.0 : sin(tp) / tp) * cw * cw * scale;
+                y = y + src[s] * (float)tap;
+            }
+        }
+        dst[j] = y;
+    }
+}
+
+}  // namespace sttfe
+
+using namespace sttfe;
+
+namespace {
+constexpr int64_t kAlignFloats = 64;
+int64_t align_up(int64_t v) { return (v + kAlignFloats - 1) / kAlignFloats * kAlignFloats; }
+int gcd_int(int a, int b) {
+    while (b) {
+        const int t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+}  // namespace
+
+extern "C" int sttfe_pitch_shift_plan(const int32_t* lengths, const int32_t* n_steps, int batch, int sample_rate,
+                                      int mode, int64_t* layout, size_t* workspace_bytes) {
+    if (batch < 0 || sample_rate <= 0 || !workspace_bytes) return STTFE_E_INVALID_ARG;
+    if (mode != STTFE_PITCH_AS_CONSTRUCTED && mode != STTFE_PITCH_FUNCTIONAL) return STTFE_E_INVALID_ARG;
+    if (batch > 0 && (!lengths || !n_steps || !layout)) return STTFE_E_INVALID_ARG;
+    int64_t cursor = align_up((int64_t)batch * kLayoutWords * 2);         // the device copy of the layout leads
+    for (int b = 0; b < batch; ++b) {
+        int64_t* r = layout + (int64_t)b * kLayoutWords;
+        std::memset(r, 0, sizeof(int64_t) * kLayoutWords);
+        if (n_steps[b] == STTFE_PITCH_NONE) continue;
+        const int n = lengths[b];
+        if (n <= kPvPad) return STTFE_E_INVALID_ARG;                       // reflect padding needs n > n_fft / 2 (torch.stft raises)
+        if (n_steps[b] < -48 || n_steps[b] > 48) return STTFE_E_UNSUPPORTED;
+        const double rate = std::pow(2.0, -(double)n_steps[b] / 12.0);
+        const int64_t T = 1 + n / kPvHop;
+        const int64_t T_out = rate == 1.0 ? T : (int64_t)std::ceil((double)T / rate);   // len(arange(0, T, rate))
+        const int64_t len_stretch = (int64_t)std::nearbyint((double)n / rate);           // Python round(): half to even
+        if (T_out > 0x7fffffff / kPvN || len_stretch > 0x7fffffff) return STTFE_E_UNSUPPORTED;
+        int orig = (int)((double)sample_rate / rate), neu = sample_rate;
+        const int g = gcd_int(orig, neu);
+        orig /= g;
+        neu /= g;
+        r[0] = cursor;
+        cursor += align_up(T * kPvBins * 2);
+        r[1] = cursor;
+        cursor += align_up(T_out * kPvBins * 2);
+        r[2] = cursor;
+        cursor += align_up(T_out * kPvN);
+        r[3] = cursor;
+        if (mode == STTFE_PITCH_FUNCTIONAL) cursor += align_up(len_stretch);
+        r[4] = T | (T_out << 32);
+        r[5] = (int64_t)n | (len_stretch << 32);
+        std::memcpy(&r[6], &rate, sizeof(double));
+        r[7] = (int64_t)orig | ((int64_t)neu << 32);
+    }
+    *workspace_bytes = (size_t)cursor * sizeof(float);
+    return STTFE_OK;
+}
+
+extern "C" int sttfe_pitch_shift(float* pcm, const int64_t* offsets, const int32_t* lengths, int batch,
+                                 const int64_t* layout, int mode, void* workspace, size_t workspace_bytes,
+                                 void* stream_) {
+    if (batch < 0) return STTFE_E_INVALID_ARG;
+    if (mode != STTFE_PITCH_AS_CONSTRUCTED && mode != STTFE_PITCH_FUNCTIONAL) return STTFE_E_INVALID_ARG;
+    if (batch == 0) return STTFE_OK;
+    if (!pcm || !offsets || !lengths || !layout || !workspace) return STTFE_E_INVALID_ARG;
+    if (batch > 65535) return STTFE_E_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return STTFE_E_INVALID_ARG;
+    // re-derive the extent of every row from the host layout: nothing on the device is trusted for sizes
+    int64_t need = align_up((int64_t)batch * kLayoutWords * 2);
+    int max_T = 0, max_T_out = 0, max_count = 0, active = 0;
+    for (int b = 0; b < batch; ++b) {
+        const int64_t* r = layout + (int64_t)b * kLayoutWords;
+        const int64_t T = r[4] & 0xffffffff, T_out = r[4] >> 32, n = r[5] & 0xffffffff, ls = r[5] >> 32;
+        if (T == 0) continue;
+        if (T < 0 || T_out <= 0 || n <= kPvPad || ls < 0 || T != 1 + n / kPvHop) return STTFE_E_INVALID_ARG;
+        if (r[0] != need) return STTFE_E_INVALID_ARG;
+        need += align_up(T * kPvBins * 2);
+        if (r[1] != need) return STTFE_E_INVALID_ARG;
+        need += align_up(T_out * kPvBins * 2);
+        if (r[2] != need) return STTFE_E_INVALID_ARG;
+        need += align_up(T_out * kPvN);
+        if (r[3] != need) return STTFE_E_INVALID_ARG;
+        if (mode == STTFE_PITCH_FUNCTIONAL) need += align_up(ls);
+        if ((r[7] & 0xffffffff) <= 0 || (r[7] >> 32) <= 0) return STTFE_E_INVALID_ARG;
+        ++active;
+        if (T > max_T) max_T = (int)T;
+        if (T_out > max_T_out) max_T_out = (int)T_out;
+        const int64_t cnt = n > ls ? n : ls;
+        if (cnt > max_count) max_count = (int)cnt;
+    }
+    if ((size_t)need * sizeof(float) > workspace_bytes) return STTFE_E_WORKSPACE;
+    if (active == 0) return STTFE_OK;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    (void)hipGetLastError();
+    float* ws = static_cast<float*>(workspace);
+    int64_t* dev_layout = static_cast<int64_t*>(workspace);
+    if (hip_failed(hipMemcpyAsync(dev_layout, layout, sizeof(int64_t) * kLayoutWords * batch, hipMemcpyHostToDevice,
+                                  stream), "pitch shift layout copy"))
+        return STTFE_E_LAUNCH;
+    {
+        ScopedTiming t(kTimePitchShift, stream);
+        auto pair_blocks = [](int frames) {
+            int g = ((frames + 1) / 2 + kPvWaves * 4 - 1) / (kPvWaves * 4);      // about four pairs per wave
+            return g < 1 ? 1 : (g > 1024 ? 1024 : g);
+        };
+        hipLaunchKernelGGL(pv_stft_kernel, dim3(pair_blocks(max_T), batch), dim3(64 * kPvWaves), 0, stream, pcm,
+                           offsets, lengths, dev_layout, ws);
+        hipLaunchKernelGGL(pv_stretch_kernel, dim3((kPvBins + 63) / 64, batch), dim3(64), 0, stream, lengths,
+                           dev_layout, ws);
+        hipLaunchKernelGGL(pv_frames_kernel, dim3(pair_blocks(max_T_out), batch), dim3(64 * kPvWaves), 0, stream,
+                           lengths, dev_layout, ws);
+        int bx = (max_count + 256 * 4 - 1) / (256 * 4);
+        bx = bx < 1 ? 1 : (bx > 1024 ? 1024 : bx);
+        const int to_wave = mode == STTFE_PITCH_FUNCTIONAL;
+        hipLaunchKernelGGL(pv_overlap_add_kernel, dim3(bx, batch), dim3(256), 0, stream, pcm, offsets, lengths,
+                           dev_layout, ws, to_wave);
+        if (to_wave)
+            hipLaunchKernelGGL(pv_resample_kernel, dim3(bx, batch), dim3(256), 0, stream, pcm, offsets, lengths,
+                               dev_layout, ws);
+    }
+    if (hip_failed(hipGetLastError(), "pitch shift kernel launch")) return STTFE_E_LAUNCH;
+    return STTFE_OK;
+}

@@ -19,7 +19,7 @@ std::vector<Slot> g_slots;
 size_t g_next = 0;
 bool g_enabled = false;
 const char* const kNames[kTimedKernelCount] = {"whisper_stft_mel", "whisper_clamp_mask", "kaldi_fbank",
-                                               "kaldi_cmvn", "resample_peak", "normalize_trim", "waveform_augment"};
+                                               "kaldi_cmvn", "resample_peak", "normalize_trim", "waveform_augment", "pitch_shift"};
 }  // namespace
 
 bool timing_enabled() { return g_enabled; }

@@ -103,7 +103,7 @@ class GpuFrontEnd:
                  tokenizer: Any = None, split: str = "train", feature_size: Optional[int] = None,
                  device: Optional[Union[str, torch.device]] = None,
                  max_source_positions: Optional[int] = None, max_target_positions: Optional[int] = None,
-                 noise_source: str = "device"):
+                 noise_source: str = "device", pitch_mode: str = "as_constructed"):
         self.config = config
         self.model_type = model_type.lower()
         if self.model_type not in ("whisper", "speech2text"):
@@ -118,7 +118,7 @@ class GpuFrontEnd:
         enabled = aug is not None and getattr(aug, "enabled", False)
         self.sampler = SpecAugmentSampler(aug) if enabled else None
         # src/data.py:328-329: waveform-domain augmentations sit between the preprocessor and the extractor
-        self.wave_sampler = WaveformAugmentSampler(aug, self.sample_rate, noise_source) if enabled else None
+        self.wave_sampler = WaveformAugmentSampler(aug, self.sample_rate, noise_source, pitch_mode) if enabled else None
         self.wave_augmenter = GpuWaveformAugmenter(self.wave_sampler) if enabled else None
         if self.model_type == "whisper":
             self.feature_extractor = HipWhisperFeatureExtractor(feature_size or 80, device=device)

@@ -125,10 +125,17 @@ def test_whisper_train_batch_with_waveform_and_spec_augmentation():
     for b, c in enumerate(clips):
         d = W.draw_time_domain(a, c.shape[0])
         masks = S.draw_clip_masks(80, 3000)
-        kinds |= {k for k in ("noise_factor", "speed_factor", "gain", "fade_samples") if getattr(d, k) is not None}
+        kinds |= {k for k in ("noise_factor", "speed_factor", "pitch_steps", "gain", "fade_samples")
+                  if getattr(d, k) is not None}
         e = S.apply_masks(whisper_features([W.apply_time_domain(c, d)], 80)[0], masks)
-        assert np.abs(got[b] - e).max() <= 1e-4, (b, d.speed_factor, d.gain, d.fade_samples)
-    assert len(kinds) == 4                                            # the seed exercises every built stage
+        err = np.abs(got[b] - e)
+        if d.pitch_steps in (None, 0):
+            assert err.max() <= 1e-4, (b, d.speed_factor, d.gain, d.fade_samples)
+        else:
+            # the phase vocoder's float32 phase rounding (tests/test_pitch_shift_gpu.py) leaves ~1e-4 of the peak in
+            # the waveform, which the weakest mel bins of a frame see as up to a few 1e-3 of normalised log-mel
+            assert err.max() <= 5e-3 and err.mean() <= 2e-5, (b, d.pitch_steps, float(err.max()), float(err.mean()))
+    assert len(kinds) == 5                                            # the seed exercises every stage
 
 
 def test_feature_cache_round_trip_of_gpu_features(tmp_path):
