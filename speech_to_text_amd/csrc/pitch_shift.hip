@@ -4,7 +4,7 @@
 // src/data.py:163-167 overwrites its n_steps with random.randint(-2, 2) per clip before calling it.  torchaudio
 // 2.5.1 computes (functional.pitch_shift): rate = 2^(-n_steps/12);
 //   S = stft(x, 512, hop 128, periodic hann, center / reflect)                    -> pv_stft_kernel
-//   S' = phase_vocoder(S, rate, linspace(0, pi*128, 257))                         -> pv_stretch_kernel
+//   S' = phase_vocoder(S, rate, linspace(0, pi*128, 257))                         -> pv_stretch_kernel (S kept as |S|, angle S)
 //   y = istft(S', length = round(n / rate))                                       -> pv_frames_kernel + pv_overlap_add_kernel
 //   y = resample(y, int(sr / rate) -> sr), sinc_interp_hann, width 6, rolloff .99 -> pv_resample_kernel
 //   crop / zero-pad y to n samples                                                -> fused into the last kernel
@@ -19,7 +19,7 @@
 // sttfe_pitch_shift_plan from the host's copy of the lengths) carry the offsets, so no kernel derives a size
 // from device data: a clip whose device length differs from the planned one is left untouched.
 // 512-point transforms: one wave per pair of real frames (z = x1 + i x2), 8 points per lane, three radix-8
-// Stockham passes through a 4 KB LDS panel, twiddles and window from LDS tables computed in float64.
+// Stockham passes through a 4 KB LDS panel, twiddles and window from LDS tables (sincospif of exact arguments).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -66,10 +66,10 @@ __device__ __forceinline__ PvClip load_clip(const int64_t* __restrict__ layout, 
 
 __device__ __forceinline__ void fill_tables(cf* tw, float* win) {
     for (int i = threadIdx.x; i < kPvN; i += blockDim.x) {
-        double s, c;
-        sincospi(-2.0 * (double)i / kPvN, &s, &c);
-        tw[i] = cf{(float)c, (float)s};
-        win[i] = (float)(0.5 - 0.5 * cospi(2.0 * (double)i / kPvN));       // torch.hann_window(512), periodic
+        float s, c;
+        sincospif(-2.0f * (float)i / kPvN, &s, &c);                        // arguments exact in float32
+        tw[i] = cf{c, s};
+        win[i] = 0.5f - 0.5f * cospif(2.0f * (float)i / kPvN);             // torch.hann_window(512), periodic
     }
 }
 
@@ -115,6 +115,7 @@ __global__ __launch_bounds__(64 * kPvWaves) void pv_stft_kernel(const float* __r
     const float* __restrict__ x = pcm + offsets[clip];
     cf* __restrict__ spec = reinterpret_cast<cf*>(ws + c.spec);
     cf* panel = s_panel[wave];
+    const bool polar = c.rate != 1.0;
     const int n_pairs = (c.T + 1) / 2;
     const int stride = gridDim.x * kPvWaves;
     const int trips = (n_pairs + stride - 1) / stride;
@@ -138,25 +139,43 @@ __global__ __launch_bounds__(64 * kPvWaves) void pv_stft_kernel(const float* __r
         // X1[k] = (Z[k] + conj Z[N-k]) / 2, X2[k] = (Z[k] - conj Z[N-k]) / 2i
         for (int k = lane; k < kPvBins; k += 64) {
             const cf a = panel[k], b = panel[(kPvN - k) & (kPvN - 1)];
-            if (t0 < c.T) spec[(int64_t)t0 * kPvBins + k] = cf{0.5f * (a.x + b.x), 0.5f * (a.y - b.y)};
-            if (t1 < c.T) spec[(int64_t)t1 * kPvBins + k] = cf{0.5f * (a.y + b.y), 0.5f * (b.x - a.x)};
+            cf x0{0.5f * (a.x + b.x), 0.5f * (a.y - b.y)}, x1{0.5f * (a.y + b.y), 0.5f * (b.x - a.x)};
+            if (polar) {                                                   // what the vocoder reads: abs() and angle()
+                x0 = cf{hypotf(x0.x, x0.y), atan2f(x0.y, x0.x)};
+                x1 = cf{hypotf(x1.x, x1.y), atan2f(x1.y, x1.x)};
+            }
+            if (t0 < c.T) spec[(int64_t)t0 * kPvBins + k] = x0;
+            if (t1 < c.T) spec[(int64_t)t1 * kPvBins + k] = x1;
         }
         __syncthreads();
     }
 }
 
-// ---- S' = phase_vocoder(S): one thread per (clip, bin), sequential in time (the phase is a running sum)
-__global__ __launch_bounds__(64) void pv_stretch_kernel(const int32_t* __restrict__ lengths,
-                                                        const int64_t* __restrict__ layout, float* __restrict__ ws) {
+// ---- S' = phase_vocoder(S).  S arrives as (|S|, angle S) (see pv_stft_kernel), so an element costs two loads,
+// a wrap and one sincos.  The phase of output frame j is a running sum over the frames before it.  A workgroup
+// owns 16 bins of one clip and walks the time axis in chunks of 16 segments x 16 frames: every thread computes
+// the (magnitude, phase increment) pairs of its segment into registers and their float64 sum, the segment sums
+// go through LDS, and the thread then turns its pairs into mag * (cos, sin)(float32(running sum)), the running
+// sum starting from the chunk's carry + the segments before its own.  S is read once, S' written once.
+// (torch.cumsum sums float32 in float64 on the CPU and rounds each prefix to float32; the segmented sum differs
+// from the sequential one by float64 rounding only.  cos / sin: torch takes them of the float32 prefix; here that
+// float32 value is reduced mod 2 pi in float64 first -- the fast path of sincosf, within 2e-7 of torch's.)
+constexpr int kPvSegs = 16, kPvBinsPerGroup = 16, kPvSegSteps = 16;
+__global__ __launch_bounds__(kPvSegs * kPvBinsPerGroup) void pv_stretch_kernel(const int32_t* __restrict__ lengths,
+                                                                              const int64_t* __restrict__ layout,
+                                                                              float* __restrict__ ws) {
+    __shared__ double s_sum[kPvSegs][kPvBinsPerGroup];
     const int clip = blockIdx.y;
     const PvClip c = load_clip(layout, clip);
-    if (c.T <= 0 || lengths[clip] != c.n) return;
-    const int k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= kPvBins) return;
+    if (c.T <= 0 || lengths[clip] != c.n) return;                          // uniform over the workgroup
+    const int kk = threadIdx.x & (kPvBinsPerGroup - 1), seg = threadIdx.x / kPvBinsPerGroup;
+    const int k = blockIdx.x * kPvBinsPerGroup + kk;
+    const bool live = k < kPvBins;
     const cf* __restrict__ spec = reinterpret_cast<const cf*>(ws + c.spec);
     cf* __restrict__ out = reinterpret_cast<cf*>(ws + c.stretch);
-    if (c.rate == 1.0) {                                                   // phase_vocoder returns its input
-        for (int t = 0; t < c.T_out; ++t) out[(int64_t)t * kPvBins + k] = spec[(int64_t)t * kPvBins + k];
+    if (c.rate == 1.0) {                                                   // phase_vocoder returns its input (raw S here)
+        if (live)
+            for (int t = seg; t < c.T_out; t += kPvSegs) out[(int64_t)t * kPvBins + k] = spec[(int64_t)t * kPvBins + k];
         return;
     }
     // torch.linspace(0, pi * hop, 257)[k], float32
@@ -164,24 +183,52 @@ __global__ __launch_bounds__(64) void pv_stretch_kernel(const int32_t* __restric
     const float step = end / (float)(kPvBins - 1);
     const float adv = k < kPvBins / 2 ? step * (float)k : end - step * (float)(kPvBins - 1 - k);
     const float two_pi = (float)(2.0 * M_PI);
-    auto at = [&](int t) { return t < c.T ? spec[(int64_t)t * kPvBins + k] : cf{0.f, 0.f}; };
-    const cf first = at(0);
-    double acc = 0.0;                                                      // torch.cumsum accumulates float in double on the CPU
-    float pending = atan2f(first.y, first.x);
-    for (int j = 0; j < c.T_out; ++j) {
-        const float ts = (float)((double)j * c.rate);
-        const int i0 = (int)ts;
-        const float alpha = ts - floorf(ts);
-        const cf lo = at(i0), hi = at(i0 + 1);
-        const float n0 = hypotf(lo.x, lo.y), n1 = hypotf(hi.x, hi.y);
-        float ph = atan2f(hi.y, hi.x) - atan2f(lo.y, lo.x) - adv;
-        ph = ph - two_pi * rintf(ph / two_pi);
-        ph = ph + adv;
-        acc += (double)pending;
-        pending = ph;
-        const float mag = alpha * n1 + (1.0f - alpha) * n0;
-        const float a = (float)acc;
-        out[(int64_t)j * kPvBins + k] = cf{mag * cosf(a), mag * sinf(a)};
+    auto at = [&](int t) { return t < c.T ? spec[(int64_t)t * kPvBins + k] : cf{0.f, 0.f}; };   // (abs, angle); pad = 0
+    double carry = live ? (double)at(0).y : 0.0;                           // phase_0 = angle(S[..., 0])
+    for (int jc = 0; jc < c.T_out; jc += kPvSegs * kPvSegSteps) {          // uniform trip count
+        const int j0 = jc + seg * kPvSegSteps;
+        float mg[kPvSegSteps], ph[kPvSegSteps];
+        double sum = 0.0;
+#pragma unroll
+        for (int i = 0; i < kPvSegSteps; ++i) {
+            const int j = j0 + i;
+            mg[i] = 0.f;
+            ph[i] = 0.f;
+            if (live && j < c.T_out) {
+                const float ts = (float)((double)j * c.rate);
+                const int i0 = (int)ts;
+                const float alpha = ts - floorf(ts);
+                const cf lo = at(i0), hi = at(i0 + 1);
+                float d = hi.y - lo.y - adv;
+                d = d - two_pi * rintf(d / two_pi);
+                ph[i] = d + adv;
+                mg[i] = alpha * hi.x + (1.0f - alpha) * lo.x;
+            }
+            sum += (double)ph[i];
+        }
+        s_sum[seg][kk] = sum;
+        __syncthreads();
+        double acc = carry, total = carry;
+#pragma unroll
+        for (int s = 0; s < kPvSegs; ++s) {
+            const double v = s_sum[s][kk];
+            total += v;
+            if (s < seg) acc += v;
+        }
+        carry = total;
+#pragma unroll
+        for (int i = 0; i < kPvSegSteps; ++i) {
+            const int j = j0 + i;
+            if (live && j < c.T_out) {
+                const double a = (double)(float)acc;
+                const double r = a - rint(a * (0.5 / M_PI)) * (2.0 * M_PI);
+                float sn, cs;
+                sincosf((float)r, &sn, &cs);
+                out[(int64_t)j * kPvBins + k] = cf{mg[i] * cs, mg[i] * sn};
+            }
+            acc += (double)ph[i];
+        }
+        __syncthreads();                                                   // s_sum is rewritten by the next chunk
     }
 }
 
@@ -247,7 +294,7 @@ __global__ __launch_bounds__(256) void pv_overlap_add_kernel(float* __restrict__
     const PvClip c = load_clip(layout, clip);
     if (c.T <= 0 || lengths[clip] != c.n) return;
     for (int i = threadIdx.x; i < kPvN; i += blockDim.x) {
-        const float w = (float)(0.5 - 0.5 * cospi(2.0 * (double)i / kPvN));
+        const float w = 0.5f - 0.5f * cospif(2.0f * (float)i / kPvN);
         s_w2[i] = w * w;
     }
     __syncthreads();
@@ -292,6 +339,11 @@ __global__ __launch_bounds__(256) void pv_resample_kernel(float* __restrict__ pc
     const int width = (int)ceil(6.0 * (double)c.orig / base);
     const double scale = base / (double)c.orig;
     const int64_t n_out = ((int64_t)c.neu * c.len_stretch + c.orig - 1) / c.orig;
+    // consecutive taps are base / orig apart in t: sin(pi t) and cos(pi t / 12) advance by fixed rotations (float64;
+    // 2 * width + 3 steps), so an output costs two sincos instead of two per tap
+    double rot_s, rot_c, rot_sw, rot_cw;
+    sincos(M_PI * scale, &rot_s, &rot_c);
+    sincos(M_PI * scale / 12.0, &rot_sw, &rot_cw);
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < c.n; j += gridDim.x * blockDim.x) {
         float y = 0.0f;
         if (j < n_out) {
@@ -300,17 +352,28 @@ __global__ __launch_bounds__(256) void pv_resample_kernel(float* __restrict__ pc
             const int64_t s0 = (int64_t)blk * c.orig;
             // torch: arange(0, -new, -1) / new is an int64 / int true division -> a float32 quotient
             const double phase = (double)__fdiv_rn((float)(-ph), (float)c.neu);
-            for (int d = -width - 1; d <= width + 1; ++d) {
-                const int kk = centre + d;                                 // tap position relative to the block start
-                if (kk < -width || kk >= width + c.orig) continue;        // outside the table row
+            const int kk0 = centre - width - 1;
+            double sn, cs, sw, cw;
+            {
+                const double t0 = (phase + (double)kk0 / (double)c.orig) * base;
+                sincos(t0 * M_PI, &sn, &cs);
+                sincos(t0 * M_PI / 12.0, &sw, &cw);
+            }
+            for (int d = 0; d <= 2 * width + 2; ++d) {
+                const int kk = kk0 + d;                                    // tap position relative to the block start
                 const int64_t s = s0 + kk;
-                if (s < 0 || s >= c.len_stretch) continue;                 // zero padding
-                double t = (phase + (double)kk / (double)c.orig) * base;
-                t = fmin(fmax(t, -6.0), 6.0);
-                const double cw = cos(t * M_PI / 6.0 / 2.0);
-                const double tp = t * M_PI;
-                const double tap = (tp == 0.0 ? 1.0 : sin(tp) / tp) * cw * cw * scale;
-                y = y + src[s] * (float)tap;
+                const double t = (phase + (double)kk / (double)c.orig) * base;
+                // outside the table row / zero padding / beyond the window (|t| >= 6: cos^2(pi/2) = 4e-33 in the table)
+                if (kk >= -width && kk < width + c.orig && s >= 0 && s < c.len_stretch && fabs(t) < 6.0) {
+                    const double tp = t * M_PI;
+                    const double tap = (tp == 0.0 ? 1.0 : sn / tp) * cw * cw * scale;
+                    y = y + src[s] * (float)tap;
+                }
+                const double sn2 = sn * rot_c + cs * rot_s, sw2 = sw * rot_cw + cw * rot_sw;
+                cs = cs * rot_c - sn * rot_s;
+                cw = cw * rot_cw - sw * rot_sw;
+                sn = sn2;
+                sw = sw2;
             }
         }
         dst[j] = y;
@@ -422,7 +485,8 @@ extern "C" int sttfe_pitch_shift(float* pcm, const int64_t* offsets, const int32
         };
         hipLaunchKernelGGL(pv_stft_kernel, dim3(pair_blocks(max_T), batch), dim3(64 * kPvWaves), 0, stream, pcm,
                            offsets, lengths, dev_layout, ws);
-        hipLaunchKernelGGL(pv_stretch_kernel, dim3((kPvBins + 63) / 64, batch), dim3(64), 0, stream, lengths,
+        hipLaunchKernelGGL(pv_stretch_kernel, dim3((kPvBins + kPvBinsPerGroup - 1) / kPvBinsPerGroup, batch),
+                           dim3(kPvSegs * kPvBinsPerGroup), 0, stream, lengths,
                            dev_layout, ws);
         hipLaunchKernelGGL(pv_frames_kernel, dim3(pair_blocks(max_T_out), batch), dim3(64 * kPvWaves), 0, stream,
                            lengths, dev_layout, ws);
