@@ -2,11 +2,15 @@
 oracle/pitch_shift.py (torchaudio 2.5.1's algorithm on the real torch.stft / torch.istft).  UNPINNED against a real
 torchaudio install (absent here), see tests/test_pitch_shift_cpu.py.
 
-Bar.  The phase vocoder accumulates per-bin phases to ~ pi * 128 * frames (4e5 rad for 10 s) and rounds them to
-float32 (spacing 0.03 rad there) before cos / sin, as torchaudio does; the kernel's atan2f / hypotf differ from
-torch's by an ulp, which now and then moves a rounded phase by one float32 step, i.e. changes one bin of one frame
-by 3 % of its magnitude.  Measured: max |d| 8e-5, rms 1.3e-5 on clips of peak 0.4-0.7.  Asserted: max <= 4e-4 * peak,
-rms <= 6e-5 * peak; n_steps = 0 (the vocoder returns its input: stft -> istft) <= 1e-6."""
+Bar.  The phase vocoder accumulates per-bin phases to x ~ pi * n / rate (5.6e5 rad for 10 s) and rounds them to
+float32 before cos / sin, as torchaudio does: the rounded phase sits on a grid of ulp(x) (0.06 rad at 10 s, 0.004 rad
+at 1 s).  Any two implementations whose atan2f / FFT differ by an ulp disagree on ~1e-6 rad of accumulated phase,
+which now and then tips one rounded phase to the next grid point: that bin of that frame then differs by ulp(x) of
+its magnitude (measured: one or two such glitches of 2-3 % of the peak in a 10 s clip, none below 5 s; everything
+else agrees to ~1e-5).  torchaudio on CPU vs CUDA would differ the same way, so the bar is statistical:
+    max |d| <= (ulp(pi * n / rate) + 4e-4) * peak      rms |d| <= (2e-5 + 4e-9 * n) * peak
+(measured rms: 1.7e-5 * peak at 1 s, 1.2e-4 at 5 s, 5.4e-4 at 10 s); n_steps = 0 (the vocoder returns its input:
+stft -> istft) <= 1e-6."""
 import ctypes
 
 import numpy as np
@@ -39,14 +43,16 @@ def close(got, want, steps):
     err = np.abs(got - want)
     if steps == 0:
         return err.max() <= 1e-6
-    return err.max() <= 4e-4 * peak and np.sqrt((err ** 2).mean()) <= 6e-5 * peak
+    n = got.shape[0]
+    grid = float(np.spacing(np.float32(np.pi * n / P.stretch_rate(steps))))
+    return err.max() <= (grid + 4e-4) * peak and np.sqrt((err ** 2).mean()) <= (2e-5 + 4e-9 * n) * peak
 
 
 @pytest.mark.parametrize("mode", ["as_constructed", "functional"])
 def test_batch_against_oracle(mode):
     from speech_to_text_amd.augment import GpuWaveformAugmenter, WaveformAugmentSampler
-    lens = [16000, 23457, 300, 257, 48000, 8000, 12345, 100]
-    steps = [-2, 1, 2, None, 0, -1, 2, None]
+    lens = [16000, 23457, 300, 257, 48000, 8000, 12345, 100, 160000]
+    steps = [-2, 1, 2, None, 0, -1, 2, None, 1]
     clips = [clip(n, i) for i, n in enumerate(lens)]
     p = pack(clips)
     buf = p.pcm.data_ptr()
