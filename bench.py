@@ -105,6 +105,10 @@ def main():
                     choices=["whisper80", "s2t", "resample_whisper", "resample_whisper_s16", "whisper128_aug", "corpus"])
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (0 = the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--event-stride", type=int, default=4,
+                    help="HIP events bracket every n-th launch of each kernel in the timed region: an event pair drains "
+                         "the queue around its launch (a headline step takes 1.035 ms without events, 1.109 ms with the "
+                         "four events of its two kernels), so timing every launch would cost `value` 7 %%")
     ap.add_argument("--settle-seconds", type=float, default=1.0,
                     help="untimed steps run after the W warm-up steps until this much wall time has passed: the GPU "
                          "clocks of the pool's boxes take ~30 launches to settle (1.20 -> 1.02 ms per launch)")
@@ -232,6 +236,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The event pool is created before the warm-up (and parked with a huge stride): creating it between the settle
+    # phase and the timed region left the GPU idle for 2 ms, after which the next ~15 launches ran up to 10 % slower
+    # (rocprofv3 trace: 0.98 ms per launch before the gap, 1.02 .. 1.10 .. 1.00 ms after it) -- the clocks drop that fast.
+    _lib.check(L.sttfe_timing_enable(8192))
+    _lib.check(L.sttfe_timing_set_stride(1 << 30))
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -240,7 +249,8 @@ def main():
         for _ in range(4):
             step()
         torch.cuda.synchronize()
-    _lib.check(L.sttfe_timing_enable(8192))
+    _lib.check(L.sttfe_timing_reset())
+    _lib.check(L.sttfe_timing_set_stride(max(args.event_stride, 1)))
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -262,14 +272,18 @@ def main():
         _lib.check(L.sttfe_timing_query(name.encode(), ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
 
-    tot_ms, launches = query(kernel)
+    tot_ms, timed_launches = query(kernel)
+    seen = ctypes.c_int()
+    _lib.check(L.sttfe_timing_seen(kernel.encode(), ctypes.byref(seen)))
+    launches = seen.value
     others = {k: query(k) for k in (["whisper_clamp_mask"] if kernel == "whisper_stft_mel" else []) + extra_kernels}
+    _lib.check(L.sttfe_timing_set_stride(1))
     _lib.check(L.sttfe_timing_enable(0))
 
     if rank == 0:
         n_clips_step = len(lens)
         clips_per_launch = n_clips_step * args.steps / max(launches, 1)
-        avg_ms = tot_ms / max(launches, 1)
+        avg_ms = tot_ms / max(timed_launches, 1)
         achieved = bytes_per_launch * (clips_per_launch / n_clips_step) / (avg_ms * 1e-3) / 1e9
         names = {"whisper80": "log-mel audio-sec/sec (80-mel, 30 s clips)",
                  "s2t": "Speech2Text fbank+CMVN audio-sec/sec (80-mel, 2-10 s clips)",
@@ -302,7 +316,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": profile_traffic(wl, clips_per_launch),
                          "kernel": kname, "avg_launch_ms": avg_ms, "clips_per_launch": clips_per_launch,
-                         "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "launches": launches, "timed_launches": timed_launches, "event_stride": max(args.event_stride, 1),
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
                          "other_kernels_avg_ms": {k: (v[0] / max(v[1], 1)) for k, v in others.items()},
                          "whole_step_frac": bytes_per_launch * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
         }

@@ -227,6 +227,12 @@ int sttfe_set_whisper_tiles_per_block(int tiles);
  */
 int sttfe_timing_enable(int capacity);
 int sttfe_timing_reset(void);
+/* Time only every stride-th launch of each kernel (default 1).  An event pair drains the queue around the launch it
+ * brackets (about 35 us per pair on MI355X), so a benchmark that also reports throughput over the same region
+ * samples the launches instead of timing all of them. */
+int sttfe_timing_set_stride(int stride);
+/* Launches of the named kernel since the last enable / reset / set_stride, whether timed or skipped by the stride. */
+int sttfe_timing_seen(const char* name, int* launches);
 int sttfe_timing_query(const char* name, double* total_ms, int* launches);
 
 #ifdef __cplusplus

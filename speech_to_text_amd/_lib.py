@@ -36,6 +36,8 @@ def _declare(lib):
         "sttfe_set_whisper_tiles_per_block": [c_int],
         "sttfe_timing_enable": [c_int],
         "sttfe_timing_reset": [],
+        "sttfe_timing_set_stride": [c_int],
+        "sttfe_timing_seen": [c_char_p, POINTER(c_int)],
         "sttfe_timing_query": [c_char_p, POINTER(ctypes.c_double), POINTER(c_int)],
         "sttfe_kaldi_tables_bytes": [c_int, POINTER(c_size_t)],
         "sttfe_kaldi_tables_build": [c_int, p, c_size_t],
