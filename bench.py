@@ -241,11 +241,22 @@ def main():
     # (rocprofv3 trace: 0.98 ms per launch before the gap, 1.02 .. 1.10 .. 1.00 ms after it) -- the clocks drop that fast.
     _lib.check(L.sttfe_timing_enable(8192))
     _lib.check(L.sttfe_timing_set_stride(1 << 30))
+    barrier()                    # N > 1: the communicator is set up here, not in front of the timed region
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < args.settle_seconds:      # untimed, like the warm-up steps
+    flag = torch.zeros(1, dtype=torch.int32, device=red_device) if dist is not None else None
+    while True:                                                       # untimed, like the warm-up steps
+        done = time.perf_counter() - t_settle >= args.settle_seconds
+        if dist is not None:
+            # the ranks leave the settle phase in the same iteration, so that none of them idles at the barrier
+            # below while the others finish (an idle GPU drops its clocks within a millisecond or two)
+            flag.fill_(1 if done else 0)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            done = bool(flag.item())
+        if done:
+            break
         for _ in range(4):
             step()
         torch.cuda.synchronize()
