@@ -203,7 +203,7 @@ int sttfe_waveform_augment(float* pcm, const int64_t* offsets, const int32_t* le
  * samples cannot be shifted (torch.stft's reflect padding raises there): STTFE_E_INVALID_ARG.
  * sttfe_pitch_shift: `layout` is that HOST array (validated against workspace_bytes, then copied to the head of the
  * workspace on `stream`); `lengths` are the device lengths -- a clip whose device length differs from the planned
- * one is left untouched.  workspace must be 16-byte aligned.  About 9 MB of workspace per 10 s clip. */
+ * one is left untouched.  workspace must be 16-byte aligned.  About 6 MB of workspace per 10 s clip. */
 #define STTFE_PITCH_NONE (-2147483647 - 1)
 #define STTFE_PITCH_AS_CONSTRUCTED 0
 #define STTFE_PITCH_FUNCTIONAL 1

@@ -5,7 +5,7 @@
 // 2.5.1 computes (functional.pitch_shift): rate = 2^(-n_steps/12);
 //   S = stft(x, 512, hop 128, periodic hann, center / reflect)                    -> pv_stft_kernel
 //   S' = phase_vocoder(S, rate, linspace(0, pi*128, 257))                         -> pv_stretch_kernel (S kept as |S|, angle S)
-//   y = istft(S', length = round(n / rate))                                       -> pv_frames_kernel + pv_overlap_add_kernel
+//   y = istft(S', length = round(n / rate))                                       -> pv_synth_kernel
 //   y = resample(y, int(sr / rate) -> sr), sinc_interp_hann, width 6, rolloff .99 -> pv_resample_kernel
 //   crop / zero-pad y to n samples                                                -> fused into the last kernel
 // STTFE_PITCH_AS_CONSTRUCTED is what the reference's transform object does: its orig_freq is fixed in the
@@ -14,8 +14,8 @@
 // Parity unpinned (torchaudio absent): restated from the algorithm text; oracle/pitch_shift.py runs the same
 // steps on the real torch.stft / torch.istft.
 //
-// Data: per active clip the workspace holds S [T][257] complex, S' [T'][257] complex, the windowed inverse
-// frames [T'][512] and (functional mode) the stretched waveform; `layout` rows (built on the host by
+// Data: per active clip the workspace holds S [T][257] (abs, angle), S' [T'][257] complex and (functional mode)
+// the stretched waveform; `layout` rows (built on the host by
 // sttfe_pitch_shift_plan from the host's copy of the lengths) carry the offsets, so no kernel derives a size
 // from device data: a clip whose device length differs from the planned one is left untouched.
 // 512-point transforms: one wave per pair of real frames (z = x1 + i x2), 8 points per lane, three radix-8
@@ -37,7 +37,7 @@ namespace sttfe {
 
 constexpr int kPvN = 512, kPvHop = 128, kPvBins = 257, kPvPad = 256;
 constexpr int kPvWaves = 4;
-constexpr int kLayoutWords = 8;        // int64 per clip: spec, stretch, frames, wave offsets (floats); T | T'<<32;
+constexpr int kLayoutWords = 8;        // int64 per clip: spec, stretch, (unused), wave offsets (floats); T | T'<<32;
                                        // n | len_stretch<<32; rate (double bits); orig | new<<32 (reduced rates)
 
 struct PvClip {
@@ -73,8 +73,14 @@ __device__ __forceinline__ void fill_tables(cf* tw, float* win) {
     }
 }
 
-// Forward 512-point DFT of the panel (natural order in and out).  Every wave of the workgroup must call it the
-// same number of times (workgroup barriers inside).
+// A wave's LDS panel is private to it: its own writes and reads only need ordering within the wave.
+__device__ __forceinline__ void wave_panel_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Forward 512-point DFT of the calling wave's panel (natural order in and out).
 __device__ __forceinline__ void fft512_panel(cf* __restrict__ panel, const cf* __restrict__ tw, int lane) {
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {
@@ -90,10 +96,10 @@ __device__ __forceinline__ void fft512_panel(cf* __restrict__ panel, const cf* _
         }
         dft8(v);
         const int j0 = (lane - k) * 8 + k;
-        __syncthreads();
+        wave_panel_sync();
 #pragma unroll
         for (int r = 0; r < 8; ++r) panel[j0 + r * ns] = v[r];
-        __syncthreads();
+        wave_panel_sync();
     }
 }
 
@@ -119,8 +125,9 @@ __global__ __launch_bounds__(64 * kPvWaves) void pv_stft_kernel(const float* __r
     const int n_pairs = (c.T + 1) / 2;
     const int stride = gridDim.x * kPvWaves;
     const int trips = (n_pairs + stride - 1) / stride;
-    for (int it = 0; it < trips; ++it) {
-        const int pair = it * stride + blockIdx.x * kPvWaves + wave;
+    // the samples of a wave's next pair are requested before the transform of the current one (HBM latency under it)
+    float xa[8], xb[8];
+    auto fetch = [&](int pair) {
         const int t0 = 2 * pair, t1 = t0 + 1;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -130,11 +137,23 @@ __global__ __launch_bounds__(64 * kPvWaves) void pv_stft_kernel(const float* __r
                 int idx = t * kPvHop + i - kPvPad;
                 if (idx < 0) idx = -idx;
                 if (idx >= c.n) idx = 2 * (c.n - 1) - idx;
-                return x[idx] * s_win[i];
+                return x[idx];
             };
-            panel[i] = cf{sample(t0), sample(t1)};
+            xa[r] = sample(t0);
+            xb[r] = sample(t1);
         }
-        __syncthreads();
+    };
+    fetch(blockIdx.x * kPvWaves + wave);
+    for (int it = 0; it < trips; ++it) {
+        const int pair = it * stride + blockIdx.x * kPvWaves + wave;
+        const int t0 = 2 * pair, t1 = t0 + 1;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = lane + 64 * r;
+            panel[i] = cf{xa[r] * s_win[i], xb[r] * s_win[i]};
+        }
+        if (it + 1 < trips) fetch(pair + stride);
+        wave_panel_sync();
         fft512_panel(panel, s_tw, lane);
         // X1[k] = (Z[k] + conj Z[N-k]) / 2, X2[k] = (Z[k] - conj Z[N-k]) / 2i
         for (int k = lane; k < kPvBins; k += 64) {
@@ -147,7 +166,7 @@ __global__ __launch_bounds__(64 * kPvWaves) void pv_stft_kernel(const float* __r
             if (t0 < c.T) spec[(int64_t)t0 * kPvBins + k] = x0;
             if (t1 < c.T) spec[(int64_t)t1 * kPvBins + k] = x1;
         }
-        __syncthreads();
+        wave_panel_sync();
     }
 }
 
@@ -189,21 +208,29 @@ __global__ __launch_bounds__(kPvSegs * kPvBinsPerGroup) void pv_stretch_kernel(c
         const int j0 = jc + seg * kPvSegSteps;
         float mg[kPvSegSteps], ph[kPvSegSteps];
         double sum = 0.0;
+        // all 32 loads of the segment are issued before the first use: addresses are clamped instead of branched
+        // around (rows >= T are the zero padding of torch's pad(S, [0, 2]); dead lanes and steps read row 0)
+        cf lo[kPvSegSteps], hi[kPvSegSteps];
+        float al[kPvSegSteps];
+        const int kc = live ? k : 0;
 #pragma unroll
         for (int i = 0; i < kPvSegSteps; ++i) {
-            const int j = j0 + i;
-            mg[i] = 0.f;
-            ph[i] = 0.f;
-            if (live && j < c.T_out) {
-                const float ts = (float)((double)j * c.rate);
-                const int i0 = (int)ts;
-                const float alpha = ts - floorf(ts);
-                const cf lo = at(i0), hi = at(i0 + 1);
-                float d = hi.y - lo.y - adv;
-                d = d - two_pi * rintf(d / two_pi);
-                ph[i] = d + adv;
-                mg[i] = alpha * hi.x + (1.0f - alpha) * lo.x;
-            }
+            const int j = min(j0 + i, c.T_out - 1);
+            const float ts = (float)((double)j * c.rate);
+            const int i0 = (int)ts;
+            al[i] = ts - floorf(ts);
+            lo[i] = spec[(int64_t)min(i0, c.T - 1) * kPvBins + kc];
+            hi[i] = spec[(int64_t)min(i0 + 1, c.T - 1) * kPvBins + kc];
+            if (i0 >= c.T) lo[i] = cf{0.f, 0.f};
+            if (i0 + 1 >= c.T) hi[i] = cf{0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < kPvSegSteps; ++i) {
+            const bool on = live && j0 + i < c.T_out;
+            float d = hi[i].y - lo[i].y - adv;
+            d = d - two_pi * rintf(d / two_pi);
+            ph[i] = on ? d + adv : 0.f;
+            mg[i] = on ? al[i] * hi[i].x + (1.0f - al[i]) * lo[i].x : 0.f;
             sum += (double)ph[i];
         }
         s_sum[seg][kk] = sum;
@@ -232,90 +259,119 @@ __global__ __launch_bounds__(kPvSegs * kPvBinsPerGroup) void pv_stretch_kernel(c
     }
 }
 
-// ---- windowed inverse frames: irfft(S'[t]) * window, two frames per 512-point transform
-__global__ __launch_bounds__(64 * kPvWaves) void pv_frames_kernel(const int32_t* __restrict__ lengths,
-                                                                  const int64_t* __restrict__ layout,
-                                                                  float* __restrict__ ws) {
+// ---- y = istft(S'): inverse transforms, window, overlap-add, window envelope, trim by n_fft / 2, cut or zero-pad
+// to `count` samples -- one kernel, the windowed frames never leave LDS.  A workgroup owns kPvRun hops (3072
+// samples) of the output: the kPvRun + 3 frames that cover them are inverse-transformed into LDS (two frames per
+// 512-point transform: Z = ext(S0) + i ext(S1), ifft(Z) = conj(fft(conj Z)) / N), then every thread gathers groups of
+// four consecutive samples from the (at most four) frames over them, in ascending frame order like torch's fold,
+// and divides by the summed squared window.  The three halo frames are transformed by two workgroups (+ 12 %
+// transforms) in exchange for not writing and re-reading 2048 bytes per frame.
+// as-constructed mode: dst = the clip itself, count = n; functional mode: dst = the wave buffer, count = len_stretch.
+constexpr int kPvRun = 24, kPvSlots = kPvRun + 3;
+__global__ __launch_bounds__(64 * kPvWaves, 2) void pv_synth_kernel(float* __restrict__ pcm,
+                                                                    const int64_t* __restrict__ offsets,
+                                                                    const int32_t* __restrict__ lengths,
+                                                                    const int64_t* __restrict__ layout,
+                                                                    float* __restrict__ ws, int to_wave) {
     __shared__ cf s_tw[kPvN];
-    __shared__ float s_win[kPvN];
+    __shared__ __attribute__((aligned(16))) float s_win[kPvN];
     __shared__ cf s_panel[kPvWaves][kPvN];
+    __shared__ __attribute__((aligned(16))) float s_frames[kPvSlots][kPvN];
     const int clip = blockIdx.y;
     const PvClip c = load_clip(layout, clip);
-    if (c.T <= 0 || lengths[clip] != c.n) return;
+    if (c.T <= 0 || lengths[clip] != c.n) return;                          // uniform over the workgroup
+    const int count = to_wave ? c.len_stretch : c.n;
+    const int m0 = blockIdx.x * (kPvHop * kPvRun);
+    if (m0 >= count) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     fill_tables(s_tw, s_win);
     __syncthreads();
     const cf* __restrict__ S = reinterpret_cast<const cf*>(ws + c.stretch);
-    float* __restrict__ frames = ws + c.frames;
+    float* __restrict__ dst = to_wave ? ws + c.wave : pcm + offsets[clip];
     cf* panel = s_panel[wave];
-    const int n_pairs = (c.T_out + 1) / 2;
-    const int stride = gridDim.x * kPvWaves;
-    const int trips = (n_pairs + stride - 1) / stride;
-    for (int it = 0; it < trips; ++it) {
-        const int pair = it * stride + blockIdx.x * kPvWaves + wave;
-        const int t0 = 2 * pair, t1 = t0 + 1;
-        // Z = ext(S0) + i ext(S1) with the Hermitian extension; the panel takes conj(Z): ifft(Z) = conj(fft(conj Z)) / N
+    // sample m sits at pos = m + 256 of the untrimmed signal; frame t covers pos in [128 t, 128 t + 512)
+    const int t_first = m0 / kPvHop - 1;                                   // (m0 + 256) / 128 - 3
+    if (m0 < c.len_stretch) {                                              // uniform; beyond it only zeros are written
+        // the bins of a wave's next pair are requested before the transform of the current one
+        cf za[8], zb[8];
+        auto fetch = [&](int pr) {
+            const int t0 = t_first + 2 * pr, t1 = t0 + 1;
+            const bool ok0 = t0 >= 0 && t0 < c.T_out, ok1 = t1 >= 0 && t1 < c.T_out && 2 * pr + 1 < kPvSlots;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int i = lane + 64 * r;
-            const int m = i <= kPvN / 2 ? i : kPvN - i;
-            const float sgn = i <= kPvN / 2 ? 1.0f : -1.0f;
-            auto bin = [&](int t) {
-                if (t >= c.T_out) return cf{0.f, 0.f};
-                cf v = S[(int64_t)t * kPvBins + m];
-                v.y = (m == 0 || m == kPvN / 2) ? 0.0f : v.y * sgn;      // c2r ignores the imaginary part of DC / Nyquist
-                return v;
-            };
-            const cf a = bin(t0), b = bin(t1);
-            panel[i] = cf{a.x - b.y, -(a.y + b.x)};
-        }
-        __syncthreads();
-        fft512_panel(panel, s_tw, lane);
+            for (int r = 0; r < 8; ++r) {
+                const int i = lane + 64 * r;
+                const int m = i <= kPvN / 2 ? i : kPvN - i;
+                za[r] = ok0 ? S[(int64_t)t0 * kPvBins + m] : cf{0.f, 0.f};
+                zb[r] = ok1 ? S[(int64_t)t1 * kPvBins + m] : cf{0.f, 0.f};
+            }
+        };
+        fetch(wave);
+        for (int pr = wave; 2 * pr < kPvSlots; pr += kPvWaves) {
+            const int t0 = t_first + 2 * pr, t1 = t0 + 1;
+            const bool ok0 = t0 >= 0 && t0 < c.T_out, ok1 = t1 >= 0 && t1 < c.T_out && 2 * pr + 1 < kPvSlots;
+            const bool any = ok0 || ok1;                                   // wave-uniform
+            if (any) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int i = lane + 64 * r;
-            const cf v = panel[i];
-            const float w = s_win[i];
-            if (t0 < c.T_out) frames[(int64_t)t0 * kPvN + i] = (v.x * (1.0f / kPvN)) * w;
-            if (t1 < c.T_out) frames[(int64_t)t1 * kPvN + i] = (-v.y * (1.0f / kPvN)) * w;
+                for (int r = 0; r < 8; ++r) {
+                    const int i = lane + 64 * r;
+                    const bool edge = i == 0 || i == kPvN / 2;           // c2r ignores the imaginary part of DC / Nyquist
+                    const float sgn = i <= kPvN / 2 ? 1.0f : -1.0f;
+                    const cf a{za[r].x, edge ? 0.0f : za[r].y * sgn}, b{zb[r].x, edge ? 0.0f : zb[r].y * sgn};
+                    panel[i] = cf{a.x - b.y, -(a.y + b.x)};
+                }
+            }
+            if (2 * (pr + kPvWaves) < kPvSlots) fetch(pr + kPvWaves);
+            if (!any) continue;
+            wave_panel_sync();
+            fft512_panel(panel, s_tw, lane);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = lane + 64 * r;
+                const cf v = panel[i];
+                const float w = s_win[i];
+                if (ok0) s_frames[2 * pr][i] = (v.x * (1.0f / kPvN)) * w;
+                if (ok1) s_frames[2 * pr + 1][i] = (-v.y * (1.0f / kPvN)) * w;
+            }
+            wave_panel_sync();
         }
-        __syncthreads();
-    }
-}
-
-// ---- overlap-add / window envelope, trimmed by n_fft/2 and cut or zero-padded to `count` samples.
-// as-constructed mode: dst = the clip itself, count = n; functional mode: dst = the wave buffer, count = len_stretch.
-__global__ __launch_bounds__(256) void pv_overlap_add_kernel(float* __restrict__ pcm, const int64_t* __restrict__ offsets,
-                                                             const int32_t* __restrict__ lengths,
-                                                             const int64_t* __restrict__ layout, float* __restrict__ ws,
-                                                             int to_wave) {
-    __shared__ float s_w2[kPvN];
-    const int clip = blockIdx.y;
-    const PvClip c = load_clip(layout, clip);
-    if (c.T <= 0 || lengths[clip] != c.n) return;
-    for (int i = threadIdx.x; i < kPvN; i += blockDim.x) {
-        const float w = 0.5f - 0.5f * cospif(2.0f * (float)i / kPvN);
-        s_w2[i] = w * w;
     }
     __syncthreads();
-    const float* __restrict__ frames = ws + c.frames;
-    float* __restrict__ dst = to_wave ? ws + c.wave : pcm + offsets[clip];
-    const int count = to_wave ? c.len_stretch : c.n;
-    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < count; m += gridDim.x * blockDim.x) {
-        float y = 0.0f;
+    const bool dst_vec = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+    for (int g = threadIdx.x; g < kPvHop * kPvRun / 4; g += blockDim.x) {
+        const int m = m0 + 4 * g;
+        if (m >= count) break;
+        float y[4] = {0.f, 0.f, 0.f, 0.f};
         if (m < c.len_stretch) {
             const int pos = m + kPvPad;
             const int t_lo = pos >= kPvN ? (pos - kPvN) / kPvHop + 1 : 0;
             int t_hi = pos / kPvHop;
             if (t_hi > c.T_out - 1) t_hi = c.T_out - 1;
-            float sum = 0.0f, env = 0.0f;
+            float sum[4] = {0.f, 0.f, 0.f, 0.f}, env[4] = {0.f, 0.f, 0.f, 0.f};
             for (int t = t_lo; t <= t_hi; ++t) {
-                sum = sum + frames[(int64_t)t * kPvN + (pos - t * kPvHop)];
-                env = env + s_w2[pos - t * kPvHop];
+                const int o = pos - t * kPvHop;
+                const float4 f = *reinterpret_cast<const float4*>(&s_frames[t - t_first][o]);
+                const float4 w = *reinterpret_cast<const float4*>(s_win + o);
+                sum[0] = sum[0] + f.x;
+                sum[1] = sum[1] + f.y;
+                sum[2] = sum[2] + f.z;
+                sum[3] = sum[3] + f.w;
+                env[0] = env[0] + w.x * w.x;
+                env[1] = env[1] + w.y * w.y;
+                env[2] = env[2] + w.z * w.z;
+                env[3] = env[3] + w.w * w.w;
             }
-            y = t_hi >= t_lo ? sum / env : 0.0f;
+            if (t_hi >= t_lo) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] = m + i < c.len_stretch ? sum[i] / env[i] : 0.0f;
+            }
         }
-        dst[m] = y;
+        if (dst_vec && m + 4 <= count) {
+            *reinterpret_cast<float4*>(dst + m) = make_float4(y[0], y[1], y[2], y[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (m + i < count) dst[m + i] = y[i];
+        }
     }
 }
 
@@ -423,8 +479,7 @@ extern "C" int sttfe_pitch_shift_plan(const int32_t* lengths, const int32_t* n_s
         cursor += align_up(T * kPvBins * 2);
         r[1] = cursor;
         cursor += align_up(T_out * kPvBins * 2);
-        r[2] = cursor;
-        cursor += align_up(T_out * kPvN);
+        r[2] = cursor;                                                     // (no frame buffer: pv_synth_kernel keeps them in LDS)
         r[3] = cursor;
         if (mode == STTFE_PITCH_FUNCTIONAL) cursor += align_up(len_stretch);
         r[4] = T | (T_out << 32);
@@ -457,9 +512,7 @@ extern "C" int sttfe_pitch_shift(float* pcm, const int64_t* offsets, const int32
         need += align_up(T * kPvBins * 2);
         if (r[1] != need) return STTFE_E_INVALID_ARG;
         need += align_up(T_out * kPvBins * 2);
-        if (r[2] != need) return STTFE_E_INVALID_ARG;
-        need += align_up(T_out * kPvN);
-        if (r[3] != need) return STTFE_E_INVALID_ARG;
+        if (r[2] != need || r[3] != need) return STTFE_E_INVALID_ARG;
         if (mode == STTFE_PITCH_FUNCTIONAL) need += align_up(ls);
         if ((r[7] & 0xffffffff) <= 0 || (r[7] >> 32) <= 0) return STTFE_E_INVALID_ARG;
         ++active;
@@ -488,13 +541,12 @@ extern "C" int sttfe_pitch_shift(float* pcm, const int64_t* offsets, const int32
         hipLaunchKernelGGL(pv_stretch_kernel, dim3((kPvBins + kPvBinsPerGroup - 1) / kPvBinsPerGroup, batch),
                            dim3(kPvSegs * kPvBinsPerGroup), 0, stream, lengths,
                            dev_layout, ws);
-        hipLaunchKernelGGL(pv_frames_kernel, dim3(pair_blocks(max_T_out), batch), dim3(64 * kPvWaves), 0, stream,
-                           lengths, dev_layout, ws);
+        const int to_wave = mode == STTFE_PITCH_FUNCTIONAL;
+        const int run = kPvHop * kPvRun;
+        hipLaunchKernelGGL(pv_synth_kernel, dim3((max_count + run - 1) / run, batch), dim3(64 * kPvWaves), 0, stream,
+                           pcm, offsets, lengths, dev_layout, ws, to_wave);
         int bx = (max_count + 256 * 4 - 1) / (256 * 4);
         bx = bx < 1 ? 1 : (bx > 1024 ? 1024 : bx);
-        const int to_wave = mode == STTFE_PITCH_FUNCTIONAL;
-        hipLaunchKernelGGL(pv_overlap_add_kernel, dim3(bx, batch), dim3(256), 0, stream, pcm, offsets, lengths,
-                           dev_layout, ws, to_wave);
         if (to_wave)
             hipLaunchKernelGGL(pv_resample_kernel, dim3(bx, batch), dim3(256), 0, stream, pcm, offsets, lengths,
                                dev_layout, ws);

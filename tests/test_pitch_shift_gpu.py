@@ -94,7 +94,7 @@ def test_c_abi_argument_checks_and_stale_lengths():
     assert L.sttfe_pitch_shift(*args(nbytes.value - 4)) == -2                          # STTFE_E_WORKSPACE
     assert L.sttfe_pitch_shift(*args(nbytes.value, mode=1)) == -1                      # layout planned for the other mode
     bad = layout.copy()
-    bad[1, 2] += 64
+    bad[1, 1] += 64
     assert L.sttfe_pitch_shift(*args(nbytes.value, lay=bad)) == -1                     # tampered layout
     p.lengths[1] = 6999                                                                # device length != planned length
     assert L.sttfe_pitch_shift(*args(nbytes.value)) == 0
