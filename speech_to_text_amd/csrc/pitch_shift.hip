@@ -172,14 +172,16 @@ __global__ __launch_bounds__(64 * kPvWaves) void pv_stft_kernel(const float* __r
 
 // ---- S' = phase_vocoder(S).  S arrives as (|S|, angle S) (see pv_stft_kernel), so an element costs two loads,
 // a wrap and one sincos.  The phase of output frame j is a running sum over the frames before it.  A workgroup
-// owns 16 bins of one clip and walks the time axis in chunks of 16 segments x 16 frames: every thread computes
-// the (magnitude, phase increment) pairs of its segment into registers and their float64 sum, the segment sums
-// go through LDS, and the thread then turns its pairs into mag * (cos, sin)(float32(running sum)), the running
-// sum starting from the chunk's carry + the segments before its own.  S is read once, S' written once.
+// owns 32 bins of one clip (256-byte runs of S and S') and walks the time axis in chunks of 8 segments x 8 frames:
+// every thread requests the 16 values of its segment at once, computes the (magnitude, phase increment) pairs into
+// registers and their float64 sum, the segment sums go through LDS, and the thread then turns its pairs into
+// mag * (cos, sin)(float32(running sum)), the running sum starting from the chunk's carry + the segments before its
+// own.  S is read once, S' written once.  (Measured: 16 bins x 16 segments x 16 frames 0.271 ms, 32 x 8 x 16
+// 0.258, 32 x 8 x 8 0.231, 32 x 8 x 4 0.234 ms on 256 x 5.5 s clips: shorter segments keep more waves resident.)
 // (torch.cumsum sums float32 in float64 on the CPU and rounds each prefix to float32; the segmented sum differs
 // from the sequential one by float64 rounding only.  cos / sin: torch takes them of the float32 prefix; here that
-// float32 value is reduced mod 2 pi in float64 first -- the fast path of sincosf, within 2e-7 of torch's.)
-constexpr int kPvSegs = 16, kPvBinsPerGroup = 16, kPvSegSteps = 16;
+// float32 value is reduced to a fraction of a turn in float64 first and given to sincospif.)
+constexpr int kPvSegs = 8, kPvBinsPerGroup = 32, kPvSegSteps = 8;
 __global__ __launch_bounds__(kPvSegs * kPvBinsPerGroup) void pv_stretch_kernel(const int32_t* __restrict__ lengths,
                                                                               const int64_t* __restrict__ layout,
                                                                               float* __restrict__ ws) {
@@ -247,10 +249,11 @@ __global__ __launch_bounds__(kPvSegs * kPvBinsPerGroup) void pv_stretch_kernel(c
         for (int i = 0; i < kPvSegSteps; ++i) {
             const int j = j0 + i;
             if (live && j < c.T_out) {
-                const double a = (double)(float)acc;
-                const double r = a - rint(a * (0.5 / M_PI)) * (2.0 * M_PI);
+                // cos / sin of float32(acc), as torch takes them, with the reduction done here in float64 turns
+                // (sincosf's own large-argument path is ~300 instructions); within 2e-7 rad of the exact value
+                const double u = (double)(float)acc * (0.5 / M_PI);
                 float sn, cs;
-                sincosf((float)r, &sn, &cs);
+                sincospif((float)(2.0 * (u - rint(u))), &sn, &cs);
                 out[(int64_t)j * kPvBins + k] = cf{mg[i] * cs, mg[i] * sn};
             }
             acc += (double)ph[i];
