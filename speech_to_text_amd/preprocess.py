@@ -13,6 +13,8 @@ import math
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Sequence, Union
 
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 import torch
 
@@ -156,9 +158,13 @@ class PinnedIngestRing:
     int16 clips stay int16 on the wire (see ``pack_planar``).
     """
 
-    def __init__(self, device: Union[str, torch.device], slots: int = 3):
+    def __init__(self, device: Union[str, torch.device], slots: int = 3, fill_threads: int = 4):
         self.device = _resolve_device(device)
         self.stream = torch.cuda.Stream(self.device)
+        # the memcpy into the pinned slot releases the GIL: a few threads fill contiguous groups of clips, and each
+        # group's H2D copy is queued as soon as it is filled (the single-threaded fill was the bound for int16 PCM)
+        self._pool = ThreadPoolExecutor(max_workers=int(fill_threads)) if int(fill_threads) > 1 else None
+        self._groups = max(2 * int(fill_threads), 1)
         self._slots: List[Optional[torch.Tensor]] = [None] * max(int(slots), 1)
         self._events: List[Optional[torch.cuda.Event]] = [None] * len(self._slots)
         self._next = 0
@@ -179,10 +185,26 @@ class PinnedIngestRing:
         if slot is None or slot.dtype != dtype or slot.numel() < total + _ALIGN:
             slot = torch.empty(max(total + _ALIGN, 1), dtype=dtype, pin_memory=True)
             self._slots[k] = slot
-        _fill_stage(slot, arrs, range(len(arrs)), starts, lens, chans)
         with torch.cuda.stream(self.stream):
             pcm = torch.empty(total + _ALIGN, dtype=dtype, device=self.device)
-            pcm.copy_(slot[:total + _ALIGN], non_blocking=True)
+            if self._pool is None or len(arrs) < 2:
+                _fill_stage(slot, arrs, range(len(arrs)), starts, lens, chans)
+                pcm.copy_(slot[:total + _ALIGN], non_blocking=True)
+            else:
+                # contiguous groups of about equal size; copies are queued in order as the fills complete
+                bounds, target, acc = [0], total / self._groups, 0
+                for i in range(len(arrs)):
+                    acc += chans * lens[i]
+                    if acc >= target * len(bounds) and i + 1 < len(arrs):
+                        bounds.append(i + 1)
+                bounds.append(len(arrs))
+                futs = [self._pool.submit(_fill_stage, slot, arrs, range(bounds[g], bounds[g + 1]), starts, lens, chans)
+                        for g in range(len(bounds) - 1)]
+                for g, f in enumerate(futs):
+                    f.result()
+                    lo = starts[bounds[g]]
+                    hi = starts[bounds[g + 1]] if bounds[g + 1] < len(arrs) else total + _ALIGN
+                    pcm[lo:hi].copy_(slot[lo:hi], non_blocking=True)
             offsets = torch.tensor(starts, dtype=torch.int64).to(self.device, non_blocking=True)
             lengths = torch.tensor(lens, dtype=torch.int32).to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
