@@ -201,16 +201,18 @@ int sttfe_waveform_augment(float* pcm, const int64_t* offsets, const int32_t* le
  * sttfe_pitch_shift_plan (host only): from the HOST copy of the clip lengths and n_steps[b] (STTFE_PITCH_NONE = leave
  * the clip alone; -48..48 otherwise) fills layout[batch][8] (int64, opaque) and the workspace size.  Clips of <= 256
  * samples cannot be shifted (torch.stft's reflect padding raises there): STTFE_E_INVALID_ARG.
- * sttfe_pitch_shift: `layout` is that HOST array (validated against workspace_bytes, then copied to the head of the
- * workspace on `stream`); `lengths` are the device lengths -- a clip whose device length differs from the planned
- * one is left untouched.  workspace must be 16-byte aligned.  About 6 MB of workspace per 10 s clip. */
+ * sttfe_pitch_shift: `layout` is that HOST array (every extent is re-derived from it and checked against
+ * workspace_bytes before anything is launched; it is not read after the call returns), `dev_layout` the caller's
+ * DEVICE copy of the same bytes, which the kernels read; `lengths` are the device lengths -- a clip whose device
+ * length differs from the planned one is left untouched.  workspace must be 16-byte aligned.  About 6 MB of
+ * workspace per 10 s clip.  Like every entry point: no allocation, no copy, no synchronisation inside. */
 #define STTFE_PITCH_NONE (-2147483647 - 1)
 #define STTFE_PITCH_AS_CONSTRUCTED 0
 #define STTFE_PITCH_FUNCTIONAL 1
 int sttfe_pitch_shift_plan(const int32_t* lengths, const int32_t* n_steps, int batch, int sample_rate, int mode,
                            int64_t* layout, size_t* workspace_bytes);
 int sttfe_pitch_shift(float* pcm, const int64_t* offsets, const int32_t* lengths, int batch, const int64_t* layout,
-                      int mode, void* workspace, size_t workspace_bytes, void* stream);
+                      const int64_t* dev_layout, int mode, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Consecutive 48-frame tiles per work item of the STFT kernel (0 = automatic, the default: the kernel derives it
  * from the clip lengths it finds on the device -- a third of the clip for uniform batches, a fifth of the

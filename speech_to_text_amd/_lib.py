@@ -54,7 +54,7 @@ def _declare(lib):
         "sttfe_normalize_trim": [p, p, p, c_int, c_int64, c_int, c_int, c_float, p, c_size_t, p],
         "sttfe_waveform_augment": [p, p, p, c_int, c_int64, p, p, p, c_int, p],
         "sttfe_pitch_shift_plan": [p, p, c_int, c_int, c_int, p, p],
-        "sttfe_pitch_shift": [p, p, p, c_int, p, c_int, p, c_size_t, p],
+        "sttfe_pitch_shift": [p, p, p, c_int, p, p, c_int, p, c_size_t, p],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name, None)

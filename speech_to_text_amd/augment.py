@@ -223,11 +223,11 @@ class GpuWaveformAugmenter:
         device = packed.pcm.device
         ws = torch.empty(max(ws_bytes.value, 16), dtype=torch.uint8, device=device)
         stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        layout_dev = torch.from_numpy(layout).to(device, non_blocking=True)
         with torch.cuda.device(device):
             _lib.check(L.sttfe_pitch_shift(_lib.ptr(packed.pcm), _lib.ptr(packed.offsets), _lib.ptr(packed.lengths), B,
-                                           layout.ctypes.data_as(ctypes.c_void_p), mode_id, _lib.ptr(ws), ws.numel(),
-                                           stream), "sttfe_pitch_shift")
-        ws.record_stream(torch.cuda.current_stream(device))
+                                           layout.ctypes.data_as(ctypes.c_void_p), _lib.ptr(layout_dev), mode_id,
+                                           _lib.ptr(ws), ws.numel(), stream), "sttfe_pitch_shift")
         return packed
 
     def apply(self, packed, draws: Sequence[WaveformDraw]):

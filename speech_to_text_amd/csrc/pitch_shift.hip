@@ -461,7 +461,7 @@ extern "C" int sttfe_pitch_shift_plan(const int32_t* lengths, const int32_t* n_s
     if (batch < 0 || sample_rate <= 0 || !workspace_bytes) return STTFE_E_INVALID_ARG;
     if (mode != STTFE_PITCH_AS_CONSTRUCTED && mode != STTFE_PITCH_FUNCTIONAL) return STTFE_E_INVALID_ARG;
     if (batch > 0 && (!lengths || !n_steps || !layout)) return STTFE_E_INVALID_ARG;
-    int64_t cursor = align_up((int64_t)batch * kLayoutWords * 2);         // the device copy of the layout leads
+    int64_t cursor = 0;
     for (int b = 0; b < batch; ++b) {
         int64_t* r = layout + (int64_t)b * kLayoutWords;
         std::memset(r, 0, sizeof(int64_t) * kLayoutWords);
@@ -495,16 +495,16 @@ extern "C" int sttfe_pitch_shift_plan(const int32_t* lengths, const int32_t* n_s
 }
 
 extern "C" int sttfe_pitch_shift(float* pcm, const int64_t* offsets, const int32_t* lengths, int batch,
-                                 const int64_t* layout, int mode, void* workspace, size_t workspace_bytes,
-                                 void* stream_) {
+                                 const int64_t* layout, const int64_t* dev_layout, int mode, void* workspace,
+                                 size_t workspace_bytes, void* stream_) {
     if (batch < 0) return STTFE_E_INVALID_ARG;
     if (mode != STTFE_PITCH_AS_CONSTRUCTED && mode != STTFE_PITCH_FUNCTIONAL) return STTFE_E_INVALID_ARG;
     if (batch == 0) return STTFE_OK;
-    if (!pcm || !offsets || !lengths || !layout || !workspace) return STTFE_E_INVALID_ARG;
+    if (!pcm || !offsets || !lengths || !layout || !dev_layout || !workspace) return STTFE_E_INVALID_ARG;
     if (batch > 65535) return STTFE_E_UNSUPPORTED;
     if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return STTFE_E_INVALID_ARG;
     // re-derive the extent of every row from the host layout: nothing on the device is trusted for sizes
-    int64_t need = align_up((int64_t)batch * kLayoutWords * 2);
+    int64_t need = 0;
     int max_T = 0, max_T_out = 0, max_count = 0, active = 0;
     for (int b = 0; b < batch; ++b) {
         const int64_t* r = layout + (int64_t)b * kLayoutWords;
@@ -529,10 +529,6 @@ extern "C" int sttfe_pitch_shift(float* pcm, const int64_t* offsets, const int32
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     (void)hipGetLastError();
     float* ws = static_cast<float*>(workspace);
-    int64_t* dev_layout = static_cast<int64_t*>(workspace);
-    if (hip_failed(hipMemcpyAsync(dev_layout, layout, sizeof(int64_t) * kLayoutWords * batch, hipMemcpyHostToDevice,
-                                  stream), "pitch shift layout copy"))
-        return STTFE_E_LAUNCH;
     {
         ScopedTiming t(kTimePitchShift, stream);
         auto pair_blocks = [](int frames) {

@@ -89,8 +89,9 @@ def test_c_abi_argument_checks_and_stale_lengths():
     assert L.sttfe_pitch_shift_plan(vp(lens), vp(st), 2, 16000, 0, vp(layout), ctypes.byref(nbytes)) == 0
     ws = torch.empty(nbytes.value, dtype=torch.uint8, device=DEV)
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    args = lambda nb, lay=layout, mode=0: (_lib.ptr(p.pcm), _lib.ptr(p.offsets), _lib.ptr(p.lengths), 2, vp(lay), mode,
-                                           _lib.ptr(ws), nb, stream)
+    lay_dev = torch.from_numpy(layout).to(DEV)
+    args = lambda nb, lay=layout, mode=0: (_lib.ptr(p.pcm), _lib.ptr(p.offsets), _lib.ptr(p.lengths), 2, vp(lay),
+                                           _lib.ptr(lay_dev), mode, _lib.ptr(ws), nb, stream)
     assert L.sttfe_pitch_shift(*args(nbytes.value - 4)) == -2                          # STTFE_E_WORKSPACE
     assert L.sttfe_pitch_shift(*args(nbytes.value, mode=1)) == -1                      # layout planned for the other mode
     bad = layout.copy()
