@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void pv_resample_kernel(float* __restrict__ pc
     }
     const double base = (double)(c.orig < c.neu ? c.orig : c.neu) * 0.99;
     const int width = (int)ceil(6.0 * (double)c.orig / base);
-    const double scale = base / (double)c.orig;
+    const double scale = base / (double)c.orig, inv_orig = 1.0 / (double)c.orig;
     const int64_t n_out = ((int64_t)c.neu * c.len_stretch + c.orig - 1) / c.orig;
     // consecutive taps are base / orig apart in t: sin(pi t) and cos(pi t / 12) advance by fixed rotations (float64;
     // 2 * width + 3 steps), so an output costs two sincos instead of two per tap
@@ -414,19 +414,21 @@ __global__ __launch_bounds__(256) void pv_resample_kernel(float* __restrict__ pc
             const int kk0 = centre - width - 1;
             double sn, cs, sw, cw;
             {
-                const double t0 = (phase + (double)kk0 / (double)c.orig) * base;
+                const double t0 = (phase + (double)kk0 * inv_orig) * base;
                 sincos(t0 * M_PI, &sn, &cs);
                 sincos(t0 * M_PI / 12.0, &sw, &cw);
             }
             for (int d = 0; d <= 2 * width + 2; ++d) {
                 const int kk = kk0 + d;                                    // tap position relative to the block start
                 const int64_t s = s0 + kk;
-                const double t = (phase + (double)kk / (double)c.orig) * base;
+                const double t = (phase + (double)kk * inv_orig) * base;
                 // outside the table row / zero padding / beyond the window (|t| >= 6: cos^2(pi/2) = 4e-33 in the table)
                 if (kk >= -width && kk < width + c.orig && s >= 0 && s < c.len_stretch && fabs(t) < 6.0) {
-                    const double tp = t * M_PI;
-                    const double tap = (tp == 0.0 ? 1.0 : sn / tp) * cw * cw * scale;
-                    y = y + src[s] * (float)tap;
+                    // sin and cos come from the float64 rotations; the quotient and the products are float32 (the
+                    // table entry is a float32 anyway: this costs one more rounding, not a float64 division per tap)
+                    const float tp = (float)(t * M_PI), cwf = (float)cw;
+                    const float sinc = tp == 0.0f ? 1.0f : (float)sn / tp;
+                    y = y + src[s] * (sinc * (cwf * cwf) * (float)scale);
                 }
                 const double sn2 = sn * rot_c + cs * rot_s, sw2 = sw * rot_cw + cw * rot_sw;
                 cs = cs * rot_c - sn * rot_s;
