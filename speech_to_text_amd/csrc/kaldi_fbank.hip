@@ -401,17 +401,35 @@ __global__ __launch_bounds__(256) void kaldi_cmvn_kernel(
     }
     __syncthreads();
     const bool no_cmvn = flags & STTFE_KALDI_NO_CMVN;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int t = e / n_mels, mel = e - t * n_mels;
-        float y = 0.0f;
-        if (t < T) {
-            y = no_cmvn ? o[e] : (o[e] - s_mean[mel]) / s_std[mel];
-            for (int i = 0; i < nm; ++i) {
-                const int idx = (m_axis[i] == STTFE_AXIS_TIME) ? t : mel;
-                if (idx >= m_s[i] && idx < m_e[i]) y = 0.0f;
-            }
+    auto norm = [&](float x, int t, int mel) {
+        float y = no_cmvn ? x : (x - s_mean[mel]) / s_std[mel];
+        for (int i = 0; i < nm; ++i) {
+            const int idx = (m_axis[i] == STTFE_AXIS_TIME) ? t : mel;
+            if (idx >= m_s[i] && idx < m_e[i]) y = 0.0f;
         }
-        o[e] = y;
+        return y;
+    };
+    if ((n_mels & 3) == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+        // four bins of one row per thread and trip (a row is a whole number of 16-byte groups); padded rows are
+        // written without being read
+        const int groups = total >> 2, row_groups = n_mels >> 2;
+        for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += stride) {
+            const int t = g / row_groups, mel = (g - t * row_groups) << 2;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < T) {
+                v = reinterpret_cast<const float4*>(o)[g];
+                v.x = norm(v.x, t, mel);
+                v.y = norm(v.y, t, mel + 1);
+                v.z = norm(v.z, t, mel + 2);
+                v.w = norm(v.w, t, mel + 3);
+            }
+            reinterpret_cast<float4*>(o)[g] = v;
+        }
+    } else {
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+            const int t = e / n_mels, mel = e - t * n_mels;
+            o[e] = t < T ? norm(o[e], t, mel) : 0.0f;
+        }
     }
     if (attn) {
         for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < t_max; t += stride) {
