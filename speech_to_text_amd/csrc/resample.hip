@@ -84,58 +84,68 @@ __global__ __launch_bounds__(rs::kThreads) void decimate_peak_kernel(
     const int width = plan->width;
     float peak = 0.f;
 
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
+    // padded[ORIG * o0 + g] = x[ORIG * o0 + g - width] (zero outside the clip) -> rows[g % ORIG][g / ORIG].
+    // All loads of a tile are issued together (one HBM round trip per tile, not one per element: the compiler cannot
+    // move a load above an LDS store of the loop before it), and a tile ahead: the next tile's samples are requested
+    // right after this tile's have gone to LDS and arrive under its 168 FMAs per thread.
+    // int16 mono: one aligned 32-bit load brings two samples (single 2-byte loads ran at half the rate of the float
+    // path).  Pairs are aligned in source-index space (clip starts are 4-byte aligned).
+    constexpr bool kIs16 = sizeof(TIn) == 2;
+    const bool paired = kIs16 && channels == 1 && (reinterpret_cast<uintptr_t>(x) & 3) == 0;
+    constexpr int kPairs = (ORIG * kRowLen + 2 + 1) / 2;
+    constexpr int kPairsPerThread = (kPairs + kThreads - 1) / kThreads;
+    constexpr int kPerThread = (ORIG * kRowLen + kThreads - 1) / kThreads;
+    uint32_t stage2[kIs16 ? kPairsPerThread : 1];
+    float stage[kPerThread];
+    auto request = [&](int tile) {
         const int o0 = tile * kTile;
-        __syncthreads();                                            // previous tile's row reads are done
-        // padded[ORIG * o0 + g] = x[ORIG * o0 + g - width] (zero outside the clip) -> rows[g % ORIG][g / ORIG].
-        // All loads of the tile are issued before the first LDS write (one HBM round trip per tile, not one
-        // per element: the compiler cannot move a load above an LDS store of the loop before it).
-        if constexpr (sizeof(TIn) == 2) {
-            // int16 mono: one aligned 32-bit load brings two samples (single 2-byte loads ran at half the rate of
-            // the float path).  Pairs are aligned in source-index space (clip starts are 4-byte aligned).
-            if (channels == 1 && (reinterpret_cast<uintptr_t>(x) & 3) == 0) {
-                const int base = ORIG * o0 - width;                 // source index of g = 0
-                const int e_base = base & ~1;                       // even (floor also for negative base)
-                constexpr int kPairs = (ORIG * kRowLen + 2 + 1) / 2;
-                constexpr int kPairsPerThread = (kPairs + kThreads - 1) / kThreads;
-                uint32_t stage2[kPairsPerThread];
+        if (kIs16 && paired) {
+            const int base = ORIG * o0 - width;                     // source index of g = 0
+            const int e_base = base & ~1;                           // even (floor also for negative base)
 #pragma unroll
-                for (int i = 0; i < kPairsPerThread; ++i) {
-                    const int e = e_base + 2 * (tid + i * kThreads);
-                    uint32_t w = 0;
-                    if (e >= 0 && e + 1 < n) w = *reinterpret_cast<const uint32_t*>(x + e);
-                    else if (e >= 0 && e < n) w = (uint16_t)x[e];
-                    else if (e + 1 >= 0 && e + 1 < n) w = (uint32_t)(uint16_t)x[e + 1] << 16;
-                    stage2[i] = w;
-                }
-#pragma unroll
-                for (int i = 0; i < kPairsPerThread; ++i) {
-                    const int g = e_base + 2 * (tid + i * kThreads) - base;
-                    const float lo = to_f32((int16_t)(stage2[i] & 0xffffu)), hi = to_f32((int16_t)(stage2[i] >> 16));
-                    if (g >= 0 && g < ORIG * kRowLen) rows[(g % ORIG) * kRowStride + g / ORIG] = lo;
-                    if (g + 1 >= 0 && g + 1 < ORIG * kRowLen) rows[((g + 1) % ORIG) * kRowStride + (g + 1) / ORIG] = hi;
-                }
-                __syncthreads();
-                goto staged;
+            for (int i = 0; i < (kIs16 ? kPairsPerThread : 0); ++i) {
+                const int e = e_base + 2 * (tid + i * kThreads);
+                uint32_t w = 0;
+                if (e >= 0 && e + 1 < n) w = *reinterpret_cast<const uint32_t*>(x + e);
+                else if (e >= 0 && e < n) w = (uint16_t)x[e];
+                else if (e + 1 >= 0 && e + 1 < n) w = (uint32_t)(uint16_t)x[e + 1] << 16;
+                stage2[i] = w;
             }
-        }
-        {
-            constexpr int kPerThread = (ORIG * kRowLen + kThreads - 1) / kThreads;
-            float stage[kPerThread];
+        } else {
 #pragma unroll
             for (int i = 0; i < kPerThread; ++i) {
                 const int g = tid + i * kThreads;
                 const int src = ORIG * o0 + g - width;
                 stage[i] = (g < ORIG * kRowLen && src >= 0 && src < n) ? mono_at(x, n, channels, src) : 0.f;
             }
+        }
+    };
+    auto deposit = [&](int tile) {
+        if (kIs16 && paired) {
+            const int base = ORIG * tile * kTile - width;
+            const int e_base = base & ~1;
+#pragma unroll
+            for (int i = 0; i < (kIs16 ? kPairsPerThread : 0); ++i) {
+                const int g = e_base + 2 * (tid + i * kThreads) - base;
+                const float lo = to_f32((int16_t)(stage2[i] & 0xffffu)), hi = to_f32((int16_t)(stage2[i] >> 16));
+                if (g >= 0 && g < ORIG * kRowLen) rows[(g % ORIG) * kRowStride + g / ORIG] = lo;
+                if (g + 1 >= 0 && g + 1 < ORIG * kRowLen) rows[((g + 1) % ORIG) * kRowStride + (g + 1) / ORIG] = hi;
+            }
+        } else {
 #pragma unroll
             for (int i = 0; i < kPerThread; ++i) {
                 const int g = tid + i * kThreads;
                 if (g < ORIG * kRowLen) rows[(g % ORIG) * kRowStride + g / ORIG] = stage[i];
             }
-            __syncthreads();
         }
-    staged:
+    };
+    request(tile_begin);
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        const int o0 = tile * kTile;
+        __syncthreads();                                            // previous tile's row reads are done
+        deposit(tile);
+        __syncthreads();
+        if (tile + 1 < tile_end) request(tile + 1);
         float acc[kOutPerThread] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < ORIG; ++r) {
