@@ -15,9 +15,9 @@
 // steps on the real torch.stft / torch.istft.
 //
 // Data: per active clip the workspace holds S [T][257] (abs, angle), S' [T'][257] complex and (functional mode)
-// the stretched waveform; `layout` rows (built on the host by
-// sttfe_pitch_shift_plan from the host's copy of the lengths) carry the offsets, so no kernel derives a size
-// from device data: a clip whose device length differs from the planned one is left untouched.
+// the stretched waveform; `layout` rows (built on the host by sttfe_pitch_shift_plan from the host's copy of the
+// lengths) carry the offsets, so no kernel derives a size from device data: a clip whose device length differs
+// from the planned one is left untouched.
 // 512-point transforms: one wave per pair of real frames (z = x1 + i x2), 8 points per lane, three radix-8
 // Stockham passes through a 4 KB LDS panel, twiddles and window from LDS tables (sincospif of exact arguments).
 #include <hip/hip_runtime.h>
@@ -41,7 +41,7 @@ constexpr int kLayoutWords = 8;        // int64 per clip: spec, stretch, (unused
                                        // n | len_stretch<<32; rate (double bits); orig | new<<32 (reduced rates)
 
 struct PvClip {
-    int64_t spec, stretch, frames, wave;
+    int64_t spec, stretch, wave;
     int T, T_out, n, len_stretch;
     double rate;
     int orig, neu;
@@ -52,7 +52,6 @@ __device__ __forceinline__ PvClip load_clip(const int64_t* __restrict__ layout, 
     PvClip c;
     c.spec = r[0];
     c.stretch = r[1];
-    c.frames = r[2];
     c.wave = r[3];
     c.T = (int)(r[4] & 0xffffffff);
     c.T_out = (int)(r[4] >> 32);
@@ -519,7 +518,12 @@ extern "C" int sttfe_pitch_shift(float* pcm, const int64_t* offsets, const int32
         need += align_up(T_out * kPvBins * 2);
         if (r[2] != need || r[3] != need) return STTFE_E_INVALID_ARG;
         if (mode == STTFE_PITCH_FUNCTIONAL) need += align_up(ls);
-        if ((r[7] & 0xffffffff) <= 0 || (r[7] >> 32) <= 0) return STTFE_E_INVALID_ARG;
+        if ((r[7] & 0xffffffff) <= 0 || (r[7] >> 32) <= 0 || (r[7] & 0xffffffff) > (1 << 24) || (r[7] >> 32) > (1 << 24))
+            return STTFE_E_INVALID_ARG;
+        double rate;
+        std::memcpy(&rate, &r[6], sizeof(double));
+        if (!(rate >= 1.0 / 16.0 && rate <= 16.0)) return STTFE_E_INVALID_ARG;             // also rejects NaN
+        if (T_out != (rate == 1.0 ? T : (int64_t)std::ceil((double)T / rate))) return STTFE_E_INVALID_ARG;
         ++active;
         if (T > max_T) max_T = (int)T;
         if (T_out > max_T_out) max_T_out = (int)T_out;

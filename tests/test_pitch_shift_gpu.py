@@ -97,6 +97,9 @@ def test_c_abi_argument_checks_and_stale_lengths():
     bad = layout.copy()
     bad[1, 1] += 64
     assert L.sttfe_pitch_shift(*args(nbytes.value, lay=bad)) == -1                     # tampered layout
+    bad = layout.copy()
+    bad[0, 6] = np.frombuffer(np.float64(-0.9).tobytes(), np.int64)[0]
+    assert L.sttfe_pitch_shift(*args(nbytes.value, lay=bad)) == -1                     # a rate no plan produces
     p.lengths[1] = 6999                                                                # device length != planned length
     assert L.sttfe_pitch_shift(*args(nbytes.value)) == 0
     torch.cuda.synchronize()
