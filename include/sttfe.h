@@ -215,8 +215,8 @@ int sttfe_pitch_shift(float* pcm, const int64_t* offsets, const int32_t* lengths
                       const int64_t* dev_layout, int mode, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Consecutive 48-frame tiles per work item of the STFT kernel (0 = automatic, the default: the kernel derives it
- * from the clip lengths it finds on the device -- a third of the clip for uniform batches, a fifth of the
- * longest clip otherwise, within [3, 21]).  Tuning knob, no counterpart in the reference. */
+ * from the clip lengths it finds on the device -- a third of the clip for uniform batches, about eight items
+ * per workgroup otherwise, within [3, 21]).  Tuning knob, no counterpart in the reference. */
 int sttfe_set_whisper_tiles_per_block(int tiles);
 
 /* ------------------------------------------------------------- measurement support -----------
