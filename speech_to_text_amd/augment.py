@@ -62,11 +62,29 @@ class SpecAugmentSampler:
         return start, start + int(value.long().item())
 
     def draw_clip(self, n_freq: int, n_time: int) -> List[Tuple[int, int, int]]:
-        """Masks of one (n_freq, n_time) clip: [] when the gate fails, else time masks then freq masks."""
+        """Masks of one (n_freq, n_time) clip: [] when the gate fails, else time masks then freq masks.
+
+        All uniform draws of the clip come from one ``torch.rand(2 k)`` call: the CPU generator hands out the same
+        numbers, in the same order and leaving the same state, as 2 k successive ``torch.rand(1)`` calls
+        (tests/test_specaugment_cpu.py pins that), and the float32 products are the same element-wise."""
         if not (self.spec_augment and random.random() < self.probability):
             return []
-        masks = [(AXIS_TIME, *self._draw(n_time, self.time_mask_max_size)) for _ in range(self.num_time_masks)]
-        masks += [(AXIS_FREQ, *self._draw(n_freq, self.freq_mask_max_size)) for _ in range(self.num_freq_masks)]
+        plan = [(AXIS_TIME, n_time, self.time_mask_max_size)] * self.num_time_masks \
+            + [(AXIS_FREQ, n_freq, self.freq_mask_max_size)] * self.num_freq_masks
+        live = [(a, n, p) for a, n, p in plan if p >= 1]      # mask_param < 1: input untouched, no draws
+        masks: List[Tuple[int, int, int]] = []
+        if live:
+            u = torch.rand(2 * len(live))
+            value = u[0::2] * torch.tensor([float(p) for _, _, p in live])
+            min_value = u[1::2] * (torch.tensor([float(n) for _, n, _ in live]) - value)
+            starts, spans = min_value.long().tolist(), value.long().tolist()
+        it = iter(range(len(live)))
+        for a, n, p in plan:
+            if p < 1:
+                masks.append((a, 0, 0))
+            else:
+                i = next(it)
+                masks.append((a, starts[i], starts[i] + spans[i]))
         return masks
 
     def mask_table(self, shapes: Sequence[Tuple[int, int]]) -> torch.Tensor:
@@ -243,7 +261,7 @@ class GpuWaveformAugmenter:
             return packed
         lens = list(packed.host_lengths)
         stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-        params = torch.zeros((B, 4), dtype=torch.int32)
+        params_np = np.zeros((B, 4), dtype=np.int32)
         keep = list(packed.keep)
         noise_dev = noise_off = None
         any_noise = any(d.noise_factor is not None for d in draws)
@@ -266,15 +284,15 @@ class GpuWaveformAugmenter:
             flags = 0
             if d.noise_factor is not None:
                 flags |= AUG_NOISE
-                params[b, 1] = _fbits(d.noise_factor)
+                params_np[b, 1] = _fbits(d.noise_factor)
             if d.gain is not None:
                 flags |= AUG_GAIN
-                params[b, 2] = _fbits(d.gain)
+                params_np[b, 2] = _fbits(d.gain)
             if d.fade_samples is not None:
                 flags |= AUG_FADE
-                params[b, 3] = int(d.fade_samples)
-            params[b, 0] = flags
-        params_dev = params.to(device, non_blocking=True)
+                params_np[b, 3] = int(d.fade_samples)
+            params_np[b, 0] = flags
+        params_dev = torch.from_numpy(params_np).to(device, non_blocking=True)
         speed_groups: Dict[Tuple[int, int], List[int]] = {}
         for b, d in enumerate(draws):
             if d.speed_factor is not None and d.speed_factor != 1.0:

@@ -213,10 +213,11 @@ class GpuFrontEnd:
                 # torchaudio's Fade raises when the fade is longer than the clip, and the reference lets it propagate
                 raise RuntimeError("fade longer than the clip (fade_duration vs min_duration)")
             pcm, offsets, lengths, host_lengths = packed.pcm, packed.offsets, packed.lengths, packed.host_lengths
-            table = torch.zeros((B, max(self.sampler.masks_per_clip, 1), 3), dtype=torch.int32)
+            table_np = np.zeros((B, max(self.sampler.masks_per_clip, 1), 3), dtype=np.int32)
             for b, masks in enumerate(rows):
-                for i, (axis, s0, e0) in enumerate(masks):
-                    table[b, i, 0], table[b, i, 1], table[b, i, 2] = axis, s0, e0
+                if masks:
+                    table_np[b, :len(masks)] = masks
+            table = torch.from_numpy(table_np)
         result: Dict[str, Any] = self.features(pcm, offsets, lengths, host_lengths, mask_table=table)
         labels = self._labels(texts)
         if labels is not None:

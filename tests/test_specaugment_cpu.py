@@ -55,3 +55,16 @@ def test_disabled_flags_consume_no_randomness():
     st = torch.get_rng_state()
     assert zero.draw_clip(80, 3000) == [(AXIS_TIME, 0, 0)] * 2 + [(AXIS_FREQ, 0, 0)] * 2
     assert torch.equal(torch.get_rng_state(), st)
+
+
+def test_bulk_uniform_draws_equal_successive_single_draws():
+    """SpecAugmentSampler.draw_clip takes a clip's uniform numbers in one torch.rand(2 k) call; the reference draws
+    them one torch.rand(1) at a time: same numbers, same order, same generator state afterwards."""
+    for n in (2, 8, 16, 17, 64):
+        torch.manual_seed(11)
+        single = torch.cat([torch.rand(1) for _ in range(n)])
+        after_single = torch.rand(1)
+        torch.manual_seed(11)
+        bulk = torch.rand(n)
+        after_bulk = torch.rand(1)
+        assert torch.equal(single, bulk) and torch.equal(after_single, after_bulk)
