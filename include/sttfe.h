@@ -76,6 +76,17 @@ int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, const int32_t
                          float* out, const int32_t* mask_tbl, int n_masks,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same features for clip_scale[b] * clip b (clip_scale: device float32 [batch], > 0), without touching the
+ * samples: rows P2 + W fused.  Replaces the pair x / (max|x| + 1e-8) (src/data.py:78-81) -> feature extractor
+ * (src/data.py:338-343) when the normalised waveform itself is not needed: with s = 1 / (peak + 1e-8) from
+ * sttfe_resample_peak's workspace, log10(max(s^2 mel, 1e-10)) = log10(max(mel, 1e-10 / s^2)) + 2 log10(s) is a
+ * per-clip floor and bias in the kernel's epilogue.  Differs from normalising first by the float32 rounding of
+ * s * x per sample (about 1e-7 in the normalised log-mel). */
+int sttfe_whisper_logmel_scaled(const float* pcm, const int64_t* offsets, const int32_t* lengths,
+                                int batch, int n_mels, int n_frames, const void* dev_tables,
+                                float* out, const int32_t* mask_tbl, int n_masks, const float* clip_scale,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------- Speech2Text Kaldi fbank + utterance CMVN (row K) ----
  * Replaces processor.feature_extractor(audio_np, sampling_rate=16000, return_tensors="pt",
  * truncation=..., max_length=...) for Speech2TextProcessor: src/data.py:346-358, plus the time

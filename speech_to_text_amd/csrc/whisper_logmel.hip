@@ -147,7 +147,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     const int32_t* __restrict__ lengths, int n_mels, int n_frames,
     const WhisperTablesHeader* __restrict__ tab, float* __restrict__ out,
     unsigned* __restrict__ keys, const int32_t* __restrict__ mask_tbl, int n_masks, int tiles_per_block,
-    int batch, unsigned* __restrict__ ticket) {
+    int batch, unsigned* __restrict__ ticket, const float* __restrict__ clip_scale) {
     using namespace wh;
     __shared__ __attribute__((aligned(16))) float smem[kLdsFloats];
 
@@ -379,6 +379,15 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
       const int64_t off_x = ((int64_t)__builtin_amdgcn_readfirstlane((int)(off_cur >> 32)) << 32) |
                             (uint32_t)__builtin_amdgcn_readfirstlane((int)off_cur);
       const float* __restrict__ x = pcm + off_x;
+      // Per-clip amplitude scale s (peak normalisation folded in, sttfe_whisper_logmel_scaled): the features of s x are
+      // log10(max(s^2 mel, 1e-10)) = log10(max(mel, 1e-10 / s^2)) + 2 log10(s) -- a floor and a bias of the epilogue,
+      // nothing per sample.  Maxima / minima (keys) stay in the unscaled domain; kernel 2 applies the same bias.
+      float mel_floor = 1e-10f, y_bias = 1.0f;
+      if (clip_scale) {
+          const float sc = clip_scale[clip];                       // workgroup-uniform address: a scalar load
+          mel_floor = 1e-10f / (sc * sc);
+          y_bias = 1.0f + 0.5f * 0.30102999566398120f * __log2f(sc);
+      }
       if (tid == 0 && next_item < n_items) my_ticket = atomicAdd(ticket, 1u);     // -> the item after the next
       if (next_item < n_items) {                   // lands while this item is processed
           len_next = lengths[next_item % batch];
@@ -510,8 +519,8 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
             float mv[4], yv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                mv[r] = fmaxf(acc[r], 1e-10f);
-                yv[r] = fmaf(__log2f(mv[r]), 0.25f * 0.30102999566398120f, 1.0f);
+                mv[r] = fmaxf(acc[r], mel_floor);
+                yv[r] = fmaf(__log2f(mv[r]), 0.25f * 0.30102999566398120f, y_bias);
             }
             const bool whole = (mt * 16 + 16 <= n_mels) && (t0 + ft * 16 + 16 <= n_frames);    // wave-uniform
             if (whole && nm == 0) {
@@ -576,7 +585,8 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 // SpecAugment masks -> 0.0 on everything written.
 __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     float* __restrict__ out, const int32_t* __restrict__ lengths, const unsigned* __restrict__ keys,
-    int n_mels, int n_frames, const int32_t* __restrict__ mask_tbl, int n_masks) {
+    int n_mels, int n_frames, const int32_t* __restrict__ mask_tbl, int n_masks,
+    const float* __restrict__ clip_scale) {
     using namespace wh;
     const int clip = blockIdx.y;
     const int row0 = blockIdx.x, row_step = gridDim.x;
@@ -595,9 +605,12 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     const int n_tiles = (n_frames + kTileFrames - 1) / kTileFrames;
     const int first_pad_tile = min(n_tiles, (n_valid + kNfft / 2 + kHop * kTileFrames - 1) / (kHop * kTileFrames));
     const int pad_frame = min(n_frames, first_pad_tile * kTileFrames);         // first frame of the constant region
-    const float lmax = kmax ? key_to_float(kmax) : -10.0f;        // no computed tile at all: log10(1e-10)
+    // scaled clips (see kernel 1): keys are log10 of the unscaled energies, stored values carry the bias c / 4 with
+    // c = 2 log10(s); the zero padding is log10(1e-10) = -10 in the scaled domain, i.e. -10 - c in the keys' domain
+    const float c_lg = clip_scale ? 2.0f * 0.30102999566398120f * __log2f(clip_scale[clip]) : 0.0f;
+    const float lmax = kmax ? key_to_float(kmax) : -10.0f - c_lg; // no computed tile at all: the floor itself
     const float floor_lg = lmax - 8.0f;
-    const float floor_y = (floor_lg + 4.0f) * 0.25f;
+    const float floor_y = (floor_lg + 4.0f) * 0.25f + 0.25f * c_lg;
     const float pad_y = fmaxf((-10.0f + 4.0f) * 0.25f, floor_y);
 
     // tiles of the clip with something below the floor (n_tiles <= 63: one 64-bit word)
@@ -733,10 +746,10 @@ extern "C" int sttfe_set_whisper_tiles_per_block(int tiles) {
     return STTFE_OK;
 }
 
-extern "C" int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, const int32_t* lengths,
-                                    int batch, int n_mels, int n_frames, const void* dev_tables,
-                                    float* out, const int32_t* mask_tbl, int n_masks,
-                                    void* workspace, size_t workspace_bytes, void* stream_) {
+static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const int32_t* lengths,
+                               int batch, int n_mels, int n_frames, const void* dev_tables,
+                               float* out, const int32_t* mask_tbl, int n_masks, const float* clip_scale,
+                               void* workspace, size_t workspace_bytes, void* stream_) {
     if (batch < 0 || n_mels < 1 || n_mels > 128 || n_frames < 1 || (n_frames & 3) || n_masks < 0 || n_masks > 8)
         return STTFE_E_INVALID_ARG;
     if (batch == 0) return STTFE_OK;
@@ -782,7 +795,7 @@ extern "C" int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, co
 #endif
         hipLaunchKernelGGL(whisper_stft_mel_kernel, dim3(grid), dim3(wh::kThreads), dyn_lds, stream,
                            pcm, offsets, lengths, n_mels, n_frames, tab, out, keys, mask_tbl, n_masks, tiles_per_block,
-                           batch, keys + (size_t)batch * wh::kKeysPerClip);
+                           batch, keys + (size_t)batch * wh::kKeysPerClip, clip_scale);
     }
     {
         ScopedTiming t(kTimeWhisperClamp, stream);
@@ -794,8 +807,26 @@ extern "C" int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, co
         }();
         const int row_split = row_split_env ? row_split_env : (n_mels > 96 ? (n_mels + 3) / 4 : (n_mels + 4) / 5);
         hipLaunchKernelGGL(whisper_clamp_fill_kernel, dim3(row_split, batch), dim3(256), 0, stream, out, lengths, keys,
-                           n_mels, n_frames, mask_tbl, n_masks);
+                           n_mels, n_frames, mask_tbl, n_masks, clip_scale);
     }
     if (hip_failed(hipGetLastError(), "whisper kernel launch")) return STTFE_E_LAUNCH;
     return STTFE_OK;
+}
+
+extern "C" int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, const int32_t* lengths,
+                                    int batch, int n_mels, int n_frames, const void* dev_tables,
+                                    float* out, const int32_t* mask_tbl, int n_masks,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    return whisper_logmel_impl(pcm, offsets, lengths, batch, n_mels, n_frames, dev_tables, out, mask_tbl, n_masks,
+                               nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int sttfe_whisper_logmel_scaled(const float* pcm, const int64_t* offsets, const int32_t* lengths,
+                                           int batch, int n_mels, int n_frames, const void* dev_tables,
+                                           float* out, const int32_t* mask_tbl, int n_masks,
+                                           const float* clip_scale, void* workspace, size_t workspace_bytes,
+                                           void* stream) {
+    if (batch > 0 && !clip_scale) return STTFE_E_INVALID_ARG;
+    return whisper_logmel_impl(pcm, offsets, lengths, batch, n_mels, n_frames, dev_tables, out, mask_tbl, n_masks,
+                               clip_scale, workspace, workspace_bytes, stream);
 }

@@ -33,6 +33,7 @@ class PackedAudio:
     host_lengths: List[int]      # the same lengths on the host
     sample_rate: int
     keep: List[bool]             # duration gate (src/data.py:95-98); False = the reference returns None
+    scale: Optional[torch.Tensor] = None      # float32 (B,) device: pending peak normalisation (defer_normalize)
 
     @property
     def durations(self) -> List[float]:
@@ -262,8 +263,13 @@ class GpuAudioPreprocessor:
 
     def run(self, pcm_in: torch.Tensor, in_offsets: torch.Tensor, in_lengths: torch.Tensor,
             host_lengths: Sequence[int], channels: int, original_sample_rate: int,
-            sync_lengths: Optional[bool] = None) -> PackedAudio:
+            sync_lengths: Optional[bool] = None, defer_normalize: bool = False) -> PackedAudio:
         """Device-resident entry: packed (planar) PCM at ``original_sample_rate`` -> PackedAudio at 16 kHz.
+
+        ``defer_normalize`` (with ``normalize``): the samples are left unnormalised and ``PackedAudio.scale`` carries
+        1 / (max|x| + 1e-8) per clip (1 for silent clips, as src/data.py:79 skips them) for
+        ``HipWhisperFeatureExtractor.extract(..., clip_scale=...)``, which folds it into the feature kernel -- one
+        pass over the waveform less.  Silence trimming is unaffected (its threshold is relative to the peak).
 
         ``sync_lengths`` (default: only when trimming) copies the trimmed lengths back to the host,
         which is what the duration gate and Speech2Text's dynamic padding need.
@@ -301,7 +307,7 @@ class GpuAudioPreprocessor:
                              _lib.ptr(pcm_out), _lib.ptr(out_offsets), _lib.ptr(out_lengths),
                              _lib.ptr(ws), ws.numel(), stream), "sttfe_resample_peak")
             _lib.check(L.sttfe_normalize_trim(_lib.ptr(pcm_out), _lib.ptr(out_offsets), _lib.ptr(out_lengths), B,
-                                              int(max(out_lens) if B else 0), int(self.normalize),
+                                              int(max(out_lens) if B else 0), int(self.normalize and not defer_normalize),
                                               int(self.trim_silence), ctypes.c_float(self.silence_threshold),
                                               _lib.ptr(ws), ws.numel(), stream), "sttfe_normalize_trim")
         self.last_peaks = ws[:4 * B].view(torch.float32)      # max|x| per clip before normalisation (debug / tests)
@@ -310,7 +316,11 @@ class GpuAudioPreprocessor:
         final_lens = [int(v) for v in out_lengths.cpu().tolist()] if sync_lengths else out_lens
         # src/data.py:75,91,95: duration = n / sample_rate after resampling (after trimming when it trimmed)
         keep = [self.min_duration <= n / self.sample_rate <= self.max_duration for n in final_lens]
-        return PackedAudio(pcm_out, out_offsets, out_lengths, final_lens, self.sample_rate, keep)
+        scale = None
+        if defer_normalize and self.normalize:
+            peaks = self.last_peaks
+            scale = torch.where(peaks > 0, 1.0 / (peaks + 1e-8), torch.ones_like(peaks))
+        return PackedAudio(pcm_out, out_offsets, out_lengths, final_lens, self.sample_rate, keep, scale)
 
     def preprocess_batch(self, clips: Sequence, original_sample_rate: int) -> PackedAudio:
         """List of (C, n) / (n,) arrays or tensors, all at ``original_sample_rate`` -> PackedAudio."""

@@ -174,8 +174,13 @@ class HipWhisperFeatureExtractor:
         return t
 
     def extract(self, pcm: torch.Tensor, offsets: torch.Tensor, lengths: torch.Tensor,
-                mask_table: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Device-resident entry: packed PCM + per-clip offsets/lengths -> (B, M, 3000) float32."""
+                mask_table: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                clip_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Device-resident entry: packed PCM + per-clip offsets/lengths -> (B, M, 3000) float32.
+
+        ``clip_scale`` (device float32 (B,)): the features of ``clip_scale[b] * clip_b`` without touching the
+        samples (``sttfe_whisper_logmel_scaled``) -- the peak normalisation of ``GpuAudioPreprocessor.run(...,
+        defer_normalize=True)`` folded into the kernel's epilogue."""
         device = pcm.device
         B = int(offsets.shape[0])
         L = _lib.lib()
@@ -191,11 +196,22 @@ class HipWhisperFeatureExtractor:
             n_masks = int(mask_table.shape[1])
         stream = torch.cuda.current_stream(device).cuda_stream
         with torch.cuda.device(device):
-            _lib.check(L.sttfe_whisper_logmel(_lib.ptr(pcm), _lib.ptr(offsets), _lib.ptr(lengths), B,
-                                              self.feature_size, self.nb_max_frames,
-                                              _lib.ptr(self._tables_on(device)), _lib.ptr(out),
-                                              _lib.ptr(mask_table), n_masks, _lib.ptr(ws), ws.numel(),
-                                              ctypes.c_void_p(stream)), "sttfe_whisper_logmel")
+            if clip_scale is None:
+                _lib.check(L.sttfe_whisper_logmel(_lib.ptr(pcm), _lib.ptr(offsets), _lib.ptr(lengths), B,
+                                                  self.feature_size, self.nb_max_frames,
+                                                  _lib.ptr(self._tables_on(device)), _lib.ptr(out),
+                                                  _lib.ptr(mask_table), n_masks, _lib.ptr(ws), ws.numel(),
+                                                  ctypes.c_void_p(stream)), "sttfe_whisper_logmel")
+            else:
+                if clip_scale.dtype != torch.float32 or clip_scale.numel() != B or clip_scale.device != device:
+                    raise ValueError("clip_scale must be a float32 tensor of B elements on the PCM's device")
+                clip_scale = clip_scale.contiguous()
+                _lib.check(L.sttfe_whisper_logmel_scaled(_lib.ptr(pcm), _lib.ptr(offsets), _lib.ptr(lengths), B,
+                                                         self.feature_size, self.nb_max_frames,
+                                                         _lib.ptr(self._tables_on(device)), _lib.ptr(out),
+                                                         _lib.ptr(mask_table), n_masks, _lib.ptr(clip_scale),
+                                                         _lib.ptr(ws), ws.numel(), ctypes.c_void_p(stream)),
+                           "sttfe_whisper_logmel_scaled")
         return out
 
     def __call__(self, raw_speech, sampling_rate: Optional[int] = None, return_tensors: Optional[str] = "pt",
