@@ -87,6 +87,21 @@ int sttfe_whisper_logmel_scaled(const float* pcm, const int64_t* offsets, const 
                                 float* out, const int32_t* mask_tbl, int n_masks, const float* clip_scale,
                                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* sttfe_whisper_logmel for callers that cannot allocate.  No counterpart in the reference: it is for code under HIP
+ * graph capture, tight serving loops and harnesses that forbid hipMalloc, which cannot size and provide the
+ * `workspace` argument above.  Same inputs, outputs and results as sttfe_whisper_logmel; the workspace (per-clip max
+ * key, per-tile min keys, work-item ticket counter) is a device array inside the library:
+ * 4 * (64 * STTFE_WHISPER_STATIC_MAX_BATCH + 16) bytes (1 MiB + 64 B) on every GPU the library runs on, held until the
+ * process ends.  batch > STTFE_WHISPER_STATIC_MAX_BATCH returns STTFE_E_UNSUPPORTED (sttfe_last_error_detail() says
+ * why).  The call allocates and frees nothing (the array's device address is looked up once per device, on the first
+ * call made with that device current).  All calls on one GPU share that GPU's array: the entry point clears the part
+ * it uses on `stream` before its kernels run, and two calls that overlap on one GPU (different streams, or different
+ * host threads on different streams) race -- serialise them, or use sttfe_whisper_logmel with separate workspaces. */
+#define STTFE_WHISPER_STATIC_MAX_BATCH 4096
+int sttfe_whisper_logmel_static(const float* pcm, const int64_t* offsets, const int32_t* lengths,
+                                int batch, int n_mels, int n_frames, const void* dev_tables,
+                                float* out, const int32_t* mask_tbl, int n_masks, void* stream);
+
 /* ------------------------------------------- Speech2Text Kaldi fbank + utterance CMVN (row K) ----
  * Replaces processor.feature_extractor(audio_np, sampling_rate=16000, return_tensors="pt",
  * truncation=..., max_length=...) for Speech2TextProcessor: src/data.py:346-358, plus the time

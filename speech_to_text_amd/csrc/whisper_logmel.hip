@@ -34,6 +34,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "../../include/sttfe.h"
@@ -819,6 +820,54 @@ extern "C" int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, co
                                     void* workspace, size_t workspace_bytes, void* stream) {
     return whisper_logmel_impl(pcm, offsets, lengths, batch, n_mels, n_frames, dev_tables, out, mask_tbl, n_masks,
                                nullptr, workspace, workspace_bytes, stream);
+}
+
+// ---- the entry point that allocates nothing (no counterpart in the reference; include/sttfe.h) ----
+// The per-call workspace of sttfe_whisper_logmel (per-clip max / per-tile min keys + the work-item ticket counter)
+// lives in a file-scope device array instead of a caller-provided buffer.  Every GPU the library runs on holds its
+// own copy of the array at its own address until the process ends; the address is looked up once per device.
+namespace sttfe {
+namespace wh {
+constexpr int kStaticMaxBatch = STTFE_WHISPER_STATIC_MAX_BATCH;
+constexpr size_t kStaticWords = (size_t)kStaticMaxBatch * kKeysPerClip + 16;     // keys + the ticket counter (64 B)
+constexpr int kMaxDevices = 64;
+}  // namespace wh
+static __device__ __align__(256) unsigned scratch[wh::kStaticWords];
+static std::mutex g_scratch_mu;
+static unsigned* g_scratch_ptr[wh::kMaxDevices] = {};     // device address of `scratch` on each device (never the name)
+}  // namespace sttfe
+
+extern "C" int sttfe_whisper_logmel_static(const float* pcm, const int64_t* offsets, const int32_t* lengths,
+                                           int batch, int n_mels, int n_frames, const void* dev_tables,
+                                           float* out, const int32_t* mask_tbl, int n_masks, void* stream) {
+    if (batch < 0) return STTFE_E_INVALID_ARG;
+    if (batch > wh::kStaticMaxBatch) {
+        std::snprintf(g_last_detail, sizeof(g_last_detail),
+                      "sttfe_whisper_logmel_static: batch %d exceeds the static workspace (%d clips)", batch,
+                      wh::kStaticMaxBatch);
+        return STTFE_E_UNSUPPORTED;
+    }
+    if (batch == 0) return STTFE_OK;
+    int dev = -1;
+    if (hip_failed(hipGetDevice(&dev), "hipGetDevice")) return STTFE_E_LAUNCH;
+    if (dev < 0 || dev >= wh::kMaxDevices) return STTFE_E_UNSUPPORTED;
+    unsigned* ws = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        if (!g_scratch_ptr[dev]) {                   // first call on this device (which is current): resolve its copy
+            void* p = nullptr;
+            if (hip_failed(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)), "hipGetSymbolAddress(scratch)") || !p)
+                return STTFE_E_LAUNCH;
+            g_scratch_ptr[dev] = reinterpret_cast<unsigned*>(p);
+        }
+        ws = g_scratch_ptr[dev];
+    }
+    // whisper_logmel_impl zeroes the part of the workspace this batch uses (hipMemsetAsync on `stream`) before the
+    // kernels read it, so whatever the previous call left behind is cleared; it calls no allocating routine.
+    size_t need = 0;
+    sttfe_whisper_workspace_bytes(batch, &need);
+    return whisper_logmel_impl(pcm, offsets, lengths, batch, n_mels, n_frames, dev_tables, out, mask_tbl, n_masks,
+                               nullptr, ws, need, stream);
 }
 
 extern "C" int sttfe_whisper_logmel_scaled(const float* pcm, const int64_t* offsets, const int32_t* lengths,
