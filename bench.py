@@ -11,7 +11,9 @@ max-over-ranks time.
 
 --workload selects the BASELINE.json configuration (default: the headline one):
   whisper80         configs[0] shape at GPU batch: 1024 x 30 s clips @16 kHz -> (1024, 80, 3000)   [headline]
-  s2t               configs[1]: Speech2Text fbank + CMVN, 256 ragged 2-10 s clips, dynamic padding
+  s2t               configs[1]: Speech2Text fbank + CMVN, 256 ragged 2-10 s clips, dynamic padding (default mode:
+                    float64 STFT + NumPy-order CMVN, bit-compatible with the HF NumPy path)
+  s2t_f32           the same in the float32-STFT mode (torchaudio-Kaldi-style arithmetic, the faster kernel)
   resample_whisper  configs[2]: 48 kHz Common-Voice-length clips -> resample + normalise -> Whisper-80, batch 512
   resample_whisper_s16  the same with int16 decoded PCM (sttfe_resample_peak_s16; SURVEY 8d: reported as its own line)
   whisper128_aug    configs[3]: Whisper 128-mel + SpecAugment masks, Common-Voice-length clips, batch 1024
@@ -102,7 +104,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="whisper80",
-                    choices=["whisper80", "s2t", "resample_whisper", "resample_whisper_s16", "whisper128_aug", "corpus"])
+                    choices=["whisper80", "s2t", "s2t_f32", "resample_whisper", "resample_whisper_s16", "whisper128_aug", "corpus"])
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (0 = the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fused-normalize", action="store_true",
@@ -153,6 +155,9 @@ def main():
     s16 = wl == "resample_whisper_s16"
     if s16:
         wl = "resample_whisper"
+    s2t_f32 = wl == "s2t_f32"
+    if s2t_f32:
+        wl = "s2t"
     seed = {"whisper80": 101, "s2t": 102, "resample_whisper": 103, "whisper128_aug": 104, "corpus": 105}[wl] * 1000 + rank
     rng = np.random.default_rng(seed)
     B = args.batch or {"whisper80": 1024, "s2t": 256, "resample_whisper": 512, "whisper128_aug": 1024, "corpus": 1024}[wl]
@@ -235,7 +240,7 @@ def main():
                     p = pre.run(pcm, offsets, lengths, host_lens, 1, 48000)
                     fe.extract(p.pcm, p.offsets, p.lengths, out=out)
     else:
-        fe = HipSpeech2TextFeatureExtractor(device=device)
+        fe = HipSpeech2TextFeatureExtractor(device=device, stft_precision="float32" if s2t_f32 else "float64")
         t_max = max(fe.num_frames(n) for n in host_lens)
         kernel, kname = "kaldi_fbank", "kaldi_fbank_kernel"
         extra_kernels = ["kaldi_cmvn"]
@@ -330,9 +335,10 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if wl == "corpus" else "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f64" if (wl == "s2t" and not s2t_f32) else "f32",
             "data": "synthetic",
             "config": {"workload": shapes[wl] + (" (int16 decoded PCM)" if s16 else "")
+                                   + ((" (float32 STFT mode)" if s2t_f32 else " (float64 STFT + NumPy-order CMVN: HF NumPy-path parity mode)") if wl == "s2t" else "")
                                    + (" (normalisation fused into the feature kernel)" if args.fused_normalize and wl == "resample_whisper" else ""), "clips_per_gpu": B, "n_mels": n_mels,
                        "sharding": f"clip-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

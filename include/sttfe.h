@@ -109,6 +109,12 @@ int sttfe_whisper_logmel_static(const float* pcm, const int64_t* offsets, const 
  * HF:models/speech_to_text/feature_extraction_speech_to_text.py:104-163 and HF:audio_utils.py:953-1017.
  */
 #define STTFE_KALDI_NO_CMVN 1      /* flags: store ln(mel) without the (x - mean) / std step */
+#define STTFE_KALDI_F64 2          /* flags: DC removal, pre-emphasis, window and the 512-point DFT in float64, spectra
+                                      rounded to complex64 afterwards -- the arithmetic of HF's NumPy path
+                                      (HF:audio_utils.py:957-993), max-abs <= 1e-4 against it on every cell.  Without the
+                                      flag those stages run in float32, as torchaudio's Kaldi fbank does
+                                      (HF:...speech_to_text.py:113-121): cells 55+ dB below their frame's peak bin then
+                                      carry the float32 STFT's noise floor. */
 
 int sttfe_kaldi_tables_bytes(int n_mels, size_t* bytes);
 int sttfe_kaldi_tables_build(int n_mels, void* host_blob, size_t bytes);

@@ -49,7 +49,9 @@ constexpr int kTwOff = kWinOff + 400;
 constexpr int kAfragOff = kTwOff + 1024;
 constexpr int kMaxAfragFloats = 0;         // the mel weights are read from global memory (L1 / L2 resident)
 constexpr int kDescOff = kAfragOff + kMaxAfragFloats;  // per wave: 8 x {kstart, nsteps, aoff, mt | ft << 8}, then the unit counts
-constexpr int kLdsFloats = kDescOff + kWaves * kMaxUnitsPerWave * 4 + kWaves;     // 74 KB: two workgroups per CU
+constexpr int kF64TabOff = kDescOff + kWaves * kMaxUnitsPerWave * 4 + kWaves + 3 & ~3;   // float64 mode: mel bands + weights
+constexpr int kMaxBandWeights = 520;       // a triangular bank over 257 bins has at most 2 non-zero weights per bin
+constexpr int kLdsFloats = kF64TabOff + 4 * 128 + 2 * kMaxBandWeights;            // 80 KB: two workgroups per CU
 constexpr int kUnitsCap = 4;               // units one wave owns: ceil(8 mel tiles x 2 frame tiles / 4 waves) at most
 constexpr float kMelFloor = 1.1920928955078125e-07f;
 }  // namespace kaldi
@@ -61,6 +63,41 @@ __device__ __forceinline__ void wave_lds_sync2() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- float64 pieces of the STTFE_KALDI_F64 mode (HF's NumPy path frames, windows and transforms in float64,
+// HF:audio_utils.py:957-988, and only then rounds each spectrum to complex64) ----
+struct cd {
+    double x, y;
+};
+__device__ __forceinline__ cd operator+(cd a, cd b) { return cd{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cd operator-(cd a, cd b) { return cd{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cd cmuld(cd a, cd b) { return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ void dft4d(cd& a0, cd& a1, cd& a2, cd& a3) {
+    const cd s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+    a0 = s02 + s13;
+    a2 = s02 - s13;
+    a1 = cd{d02.x + d13.y, d02.y - d13.x};      // d02 - i d13
+    a3 = cd{d02.x - d13.y, d02.y + d13.x};      // d02 + i d13
+}
+// 8-point forward DFT in place, natural order in / out (2 x 4 Cooley-Tukey, as dft8 of fft_core.h)
+__device__ __forceinline__ void dft8d(cd (&v)[8]) {
+    constexpr double kH = 0.70710678118654752440;
+    cd e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    cd o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    dft4d(e0, e1, e2, e3);
+    dft4d(o0, o1, o2, o3);
+    const cd w1{(o1.x + o1.y) * kH, (o1.y - o1.x) * kH};       // * (1 - i) / sqrt 2
+    const cd w2{o2.y, -o2.x};                                  // * -i
+    const cd w3{(o3.y - o3.x) * kH, -(o3.x + o3.y) * kH};      // * (-1 - i) / sqrt 2
+    v[0] = e0 + o0;
+    v[4] = e0 - o0;
+    v[1] = e1 + w1;
+    v[5] = e1 - w1;
+    v[2] = e2 + w2;
+    v[6] = e2 - w2;
+    v[3] = e3 + w3;
+    v[7] = e3 - w3;
 }
 
 __device__ __forceinline__ int kaldi_num_frames(int n, int max_frames, int t_max) {
@@ -78,6 +115,7 @@ __device__ __forceinline__ int kaldi_num_frames(int n, int max_frames, int t_max
 // item.  The loop ends after at most n_items tickets; all threads of a workgroup take the same path.
 // (Requesting the next item's ticket, length and first PCM tile an item ahead, as the Whisper kernel does, needs
 // one of the two PCM passes to be fetched late for register room and was measured slower: 0.127 ms.)
+template <bool kF64>
 __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     const float* __restrict__ pcm, const int64_t* __restrict__ offsets,
     const int32_t* __restrict__ lengths, int n_mels, int t_max, int max_frames,
@@ -166,6 +204,44 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     };
     const int prow0 = p_row(0), prow1 = p_row(1);
 
+    // float64 mode: one frame pair at a time per wave as ONE complex 512-point DFT, 8 x 8 x 8: lane l holds
+    // z[l + 64 m]; three register-resident 8-point DFTs with two transposes through an 8 KB per-wave exchange area
+    // (the part of the wave's slab that its panel rows do not cover; 16-byte complex cells, XOR-swizzled columns so
+    // that both the row-wise writes and the column-wise reads are bank-conflict free).  The lane's window column and
+    // twiddles W512^(l q), W64^((l & 7) s) stay in registers for the whole kernel.
+    double win64[7];
+    cd tw1[8], tw2[8];
+    // float64 mode uses the wave's slab as: 8 KB exchange area, then the pair's two float64 power rows (258 doubles each)
+    cd* exch = reinterpret_cast<cd*>(my_rows);
+    double* pp = reinterpret_cast<double*>(my_rows) + 1024;
+    static_assert(8192 + 4 * 258 * 8 <= kSlabFloats * 4, "float64 exchange area + power rows must fit in the wave's slab");
+    const int4k* band64 = reinterpret_cast<const int4k*>(smem + kF64TabOff);   // per mel bin {first FFT bin, bins, weight offset, 0}
+    const double* wts64 = reinterpret_cast<const double*>(smem + kF64TabOff + 4 * 128);
+    if constexpr (kF64) {
+        const double* __restrict__ t64 = reinterpret_cast<const double*>(
+            reinterpret_cast<const char*>(tab + 1) + (((size_t)tab->afrag_floats * 4 + 7) & ~(size_t)7));
+#pragma unroll
+        for (int m = 0; m < 7; ++m) win64[m] = (lane + 64 * m < kFrame) ? t64[lane + 64 * m] : 0.0;
+        {   // the float64 mel bank (bands + weights) goes to LDS once per workgroup
+            const int nm = min(tab->n_mels, 128);
+            const int4k* __restrict__ bg = reinterpret_cast<const int4k*>(t64 + kFrame + 1024);
+            const double* __restrict__ wg = t64 + kFrame + 1024 + 2 * nm;
+            int4k* bl = reinterpret_cast<int4k*>(smem + kF64TabOff);
+            double* wl = reinterpret_cast<double*>(smem + kF64TabOff + 4 * 128);
+            for (int i = tid; i < nm; i += kThreads) bl[i] = bg[i];
+            const int nw = min(tab->reserved, kMaxBandWeights);
+            for (int i = tid; i < nw; i += kThreads) wl[i] = wg[i];
+            __syncthreads();
+        }
+        const double* __restrict__ w512 = t64 + kFrame;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i1 = (lane * q) & 511, i2 = (8 * (lane & 7) * q) & 511;
+            tw1[q] = cd{w512[2 * i1], w512[2 * i1 + 1]};
+            tw2[q] = cd{w512[2 * i2], w512[2 * i2 + 1]};
+        }
+    }
+
     unsigned iter = 0;
     while (item < n_items) {
     unsigned my_ticket = 0;
@@ -184,8 +260,10 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     if (tile_begin < tile_end) {
     float* __restrict__ out_clip = out + (size_t)clip * t_max * n_mels;
     double* __restrict__ st = stats + (size_t)clip * 2 * n_mels;
-    load_pass(tile_begin * kTileFrames, 0, raw0, prv0);
-    load_pass(tile_begin * kTileFrames, 1, raw1, prv1);
+    if constexpr (!kF64) {
+        load_pass(tile_begin * kTileFrames, 0, raw0, prv0);
+        load_pass(tile_begin * kTileFrames, 1, raw1, prv1);
+    }
 
     // CMVN sums of this wave's units over the item (a wave owns the same (mel tile, frame tile) units in every tile)
     double s1[kUnitsCap], s2[kUnitsCap];
@@ -194,6 +272,141 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
 
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const int t0 = tile * kTileFrames;
+        if constexpr (kF64) {
+            // samples x[n], x[n - 1] of the pair's two frames for n = lane + 64 m (frame b starts one hop later)
+            auto load_pair = [&](int pair, float (&xa)[7], float (&xap)[7], float (&xb)[7], float (&xbp)[7]) {
+                const int base = kHop * (t0 + wave * kFramesPerWave + 2 * pair) + lane;
+#pragma unroll
+                for (int m = 0; m < 7; ++m) {
+                    const int ia = base + 64 * m, ib = ia + kHop;
+                    const bool in_frame = lane + 64 * m < kFrame;
+                    xa[m] = (in_frame && ia < n_valid) ? x[ia] : 0.0f;
+                    xap[m] = (in_frame && ia < n_valid && ia > 0) ? x[ia - 1] : 0.0f;
+                    xb[m] = (in_frame && ib < n_valid) ? x[ib] : 0.0f;
+                    xbp[m] = (in_frame && ib < n_valid) ? x[ib - 1] : 0.0f;
+                }
+            };
+            auto fft_pair = [&](int pair, const float (&xa)[7], const float (&xap)[7], const float (&xb)[7],
+                                const float (&xbp)[7]) {
+                // per-frame mean over the 400 samples (HF:audio_utils.py:979-980), float64
+                double sa = 0.0, sb = 0.0;
+#pragma unroll
+                for (int m = 0; m < 7; ++m) {
+                    sa += (double)xa[m];
+                    sb += (double)xb[m];
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    sa += __shfl_xor(sa, off, 64);
+                    sb += __shfl_xor(sb, off, 64);
+                }
+                const double mu_a = sa / 400.0, mu_b = sb / 400.0;
+                cd v[8];
+#pragma unroll
+                for (int m = 0; m < 7; ++m) {
+                    // buffer - mean; buffer[1:] -= 0.97 buffer[:-1]; buffer[0] *= 1 - 0.97; * window (:979-986)
+                    const double da = (double)xa[m] - mu_a, db = (double)xb[m] - mu_b;
+                    double ea = da - 0.97 * ((double)xap[m] - mu_a);
+                    double eb = db - 0.97 * ((double)xbp[m] - mu_b);
+                    if (m == 0 && lane == 0) {
+                        ea = da * (1.0 - 0.97);
+                        eb = db * (1.0 - 0.97);
+                    }
+                    v[m] = cd{ea * win64[m], eb * win64[m]};          // win64 is 0 past the frame
+                }
+                v[7] = cd{0.0, 0.0};
+                dft8d(v);                                             // over m: Y_l[q]
+                wave_lds_sync2();                                     // after the previous pair's reads
+                {
+                    cd* row = exch + lane * 8;
+                    const int sw = lane & 7;
+                    row[sw] = v[0];
+#pragma unroll
+                    for (int q = 1; q < 8; ++q) row[q ^ sw] = cmuld(v[q], tw1[q]);
+                }
+                wave_lds_sync2();
+                {
+                    const int l0 = lane & 7, q2 = lane >> 3;          // lane = l0 + 8 q: rows l0 + 8 l1, column q
+                    const cd* col = exch + l0 * 8 + (q2 ^ l0);
+#pragma unroll
+                    for (int l1 = 0; l1 < 8; ++l1) v[l1] = col[64 * l1];
+                    wave_lds_sync2();
+                    dft8d(v);                                         // over l1: U[l0][s][q]
+                    cd* dst = exch + q2 * 64;
+                    const int sw = l0 ^ q2;
+                    dst[sw] = v[0];
+#pragma unroll
+                    for (int s2 = 1; s2 < 8; ++s2) dst[s2 * 8 + (sw ^ s2)] = cmuld(v[s2], tw2[s2]);
+                }
+                wave_lds_sync2();
+                {
+                    const int q3 = lane & 7, s3 = lane >> 3;          // lane = q + 8 s = bin index mod 64
+                    const cd* src = exch + q3 * 64 + s3 * 8;
+                    const int sw = s3 ^ q3;
+#pragma unroll
+                    for (int l0 = 0; l0 < 8; ++l0) v[l0] = src[l0 ^ sw];
+                    dft8d(v);                                         // over l0: v[t] = Z[lane + 64 t]
+                }
+                // spectra of the two real frames: A[k] = (Z[k] + conj Z[512 - k]) / 2, B[k] = (Z[k] - conj Z[512 - k]) / 2i,
+                // each rounded to complex64 as HF stores them (:966, :988), then |.|^2 (the 1/4 is in the mel bank)
+                const int partner = (64 - lane) & 63;
+                double* prow = pp + (pair & 1) * 2 * 258 + lane;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    double qr = __shfl(v[7 - t].x, partner, 64);
+                    double qi = __shfl(v[7 - t].y, partner, 64);
+                    if (lane == 0) {
+                        qr = v[(8 - t) & 7].x;
+                        qi = v[(8 - t) & 7].y;
+                    }
+                    const double sr = (double)(float)(v[t].x + qr), dr = (double)(float)(v[t].x - qr);
+                    const double si = (double)(float)(v[t].y + qi), di = (double)(float)(v[t].y - qi);
+                    prow[64 * t] = sr * sr + di * di;                 // np.abs(complex64, dtype=float64) ** 2 (:993)
+                    prow[258 + 64 * t] = si * si + dr * dr;
+                }
+                if (lane == 0) {                                      // bin 256
+                    const double ar = (double)(float)(2.0 * v[4].x), br = (double)(float)(2.0 * v[4].y);
+                    prow[256] = ar * ar;
+                    prow[258 + 256] = br * br;
+                }
+            };
+            // mel projection and log in float64, rounded to float32 once (:998-1015), for the four frames of two pairs:
+            // lane -> (frame, mel bin); 4 n_mels outputs = five full rounds of the wave for 80 bins
+            auto mel_rows = [&](int first_pair) {
+                wave_lds_sync2();
+                for (int o = lane; o < 4 * n_mels; o += 64) {
+                    const int fr = o / n_mels, mel = o - fr * n_mels;
+                    const int4k b = band64[mel];
+                    const double* w = wts64 + b.z;
+                    const double* pr = pp + fr * 258 + b.x;
+                    double acc = 0.0;
+                    int jj = 0;
+                    for (; jj + 4 <= b.y; jj += 4) {
+                        const double w0 = w[jj], w1 = w[jj + 1], w2 = w[jj + 2], w3 = w[jj + 3];
+                        const double p0 = pr[jj], p1 = pr[jj + 1], p2 = pr[jj + 2], p3 = pr[jj + 3];
+                        acc += w0 * p0;
+                        acc += w1 * p1;
+                        acc += w2 * p2;
+                        acc += w3 * p3;
+                    }
+                    for (; jj < b.y; ++jj) acc += w[jj] * pr[jj];
+                    const int t = t0 + wave * kFramesPerWave + 2 * first_pair + fr;
+                    if (t < T) out_clip[(unsigned)(t * n_mels + mel)] = (float)log(fmax(acc, 1.192092955078125e-07));
+                }
+            };
+            float xa0[7], xp0[7], xb0[7], xq0[7], xa1[7], xp1[7], xb1[7], xq1[7];
+            load_pair(0, xa0, xp0, xb0, xq0);
+            load_pair(1, xa1, xp1, xb1, xq1);
+            fft_pair(0, xa0, xp0, xb0, xq0);
+            load_pair(2, xa0, xp0, xb0, xq0);
+            fft_pair(1, xa1, xp1, xb1, xq1);
+            load_pair(3, xa1, xp1, xb1, xq1);
+            mel_rows(0);
+            fft_pair(2, xa0, xp0, xb0, xq0);
+            fft_pair(3, xa1, xp1, xb1, xq1);
+            mel_rows(2);
+            continue;       // wave-local from PCM to log-mel: no workgroup barrier, no matrix-core phase in this mode
+        } else {
         auto stage1 = [&](int r, const float (&raw)[18], const float (&prv)[18]) {
             const int pair = 2 * r + h;
             // window column and twiddles: all LDS reads are issued before the first slab write (the compiler
@@ -279,6 +492,7 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
             load_pass(t0 + kTileFrames, 0, raw0, prv0);
             load_pass(t0 + kTileFrames, 1, raw1, prv1);
         }
+        }   // float32 transform
         __syncthreads();
 
         // ---------------- banded mel projection (frames x mels) + ln + CMVN statistics -----------
@@ -343,9 +557,10 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     }
 
     // ---------------- CMVN sums of the run: lanes l, l+16, l+32, l+48 share a mel bin ---------------
+    // (float64 mode: kaldi_stats_seq_kernel reproduces NumPy's sequential float32 reductions instead)
 #pragma unroll
     for (int u = 0; u < kUnitsCap; ++u) {
-        if (u < nu) {
+        if (!kF64 && u < nu) {
             double a = s1[u], b2 = s2[u];
             a += __shfl_xor(a, 16, 64);
             b2 += __shfl_xor(b2, 16, 64);
@@ -367,6 +582,64 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     item = (int)min(s_next[iter & 1u], (unsigned)n_items);
     ++iter;
     }   // items
+}
+
+// float64 mode: per-clip per-bin mean and standard deviation exactly as HF's utterance_cmvn computes them
+// (HF:...speech_to_text.py:150-155): NumPy reduces a (T, n_mels) float32 array over axis 0 sequentially in t with a
+// float32 accumulator, and its std is sqrt(sum((x' - sum(x') / T)^2) / T) of x' = x - mean, all float32.  For long
+// clips that mean is 1e-5 away from the exact one and bins that hardly vary over the clip (std ~ 0.01) amplify such
+// differences a hundredfold, so matching HF to 1e-4 on every cell means doing the same additions in the same order.
+// One thread per (clip, mel bin), three dependent passes over the clip's raw log-mel column; loads are batched 16 deep.
+// stats (as float32): [clip][0][mel] = mean, [clip][1][mel] = std, inside the clip's 2 * n_mels doubles of workspace.
+__global__ __launch_bounds__(64) void kaldi_stats_seq_kernel(
+    const float* __restrict__ out, const int32_t* __restrict__ lengths, float* __restrict__ stats_f32,
+    int batch, int n_mels, int t_max, int max_frames) {
+#pragma clang fp contract(off)
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= batch * n_mels) return;
+    const int clip = idx / n_mels, mel = idx - clip * n_mels;
+    const int T = kaldi_num_frames(lengths[clip], max_frames, t_max);
+    float* st = stats_f32 + (size_t)clip * 4 * n_mels;          // the clip's region is 2 * n_mels doubles
+    if (T < 1) {
+        st[mel] = 0.0f;
+        st[n_mels + mel] = 1.0f;
+        return;
+    }
+    const float* __restrict__ p = out + (size_t)clip * t_max * n_mels + mel;
+    // two batches of kDepth loads in flight: the adds of one batch run under the loads of the other (each pass is
+    // one dependent chain of T additions per thread, and a clip's 80 columns are all the parallelism there is)
+    constexpr int kDepth = 32;
+    auto sweep = [&](auto&& term) {
+        float acc = 0.0f;
+        float a[kDepth], b[kDepth];
+        auto load = [&](float (&v)[kDepth], int t0) {
+#pragma unroll
+            for (int i = 0; i < kDepth; ++i) v[i] = p[(size_t)min(t0 + i, T - 1) * n_mels];   // unconditional: no branch
+        };
+        auto consume = [&](float (&v)[kDepth], int t0) {
+#pragma unroll
+            for (int i = 0; i < kDepth; ++i) v[i] = (t0 + i < T) ? term(v[i]) : 0.0f;    // independent of the chain
+#pragma unroll
+            for (int i = 0; i < kDepth; ++i) acc = acc + v[i];                           // acc + 0.0f is exact
+        };
+        load(a, 0);
+        for (int t0 = 0; t0 < T; t0 += 2 * kDepth) {
+            load(b, t0 + kDepth);
+            consume(a, t0);
+            load(a, t0 + 2 * kDepth);
+            consume(b, t0 + kDepth);
+        }
+        return acc;
+    };
+    const float fT = (float)T;
+    const float mean = sweep([](float x) { return x; }) / fT;                              // x.mean(axis=0)
+    const float arrmean = sweep([mean](float x) { return x - mean; }) / fT;                // _var: mean of x - mean
+    const float ssq = sweep([mean, arrmean](float x) {
+        const float d = (x - mean) - arrmean;
+        return d * d;
+    });
+    st[mel] = mean;
+    st[n_mels + mel] = sqrtf(ssq / fT);
 }
 
 // out[b][t][m] <- (x - mean_m) / std_m for t < T_b, 0 for padded rows; masks <- 0; attention mask.
@@ -391,7 +664,11 @@ __global__ __launch_bounds__(256) void kaldi_cmvn_kernel(
     // per-bin mean and population std of the clip, once per workgroup (float64 sums -> float32, as NumPy's
     // float32 mean / std of HF:...speech_to_text.py:150-155 up to rounding)
     __shared__ float s_mean[128], s_std[128];
-    if ((int)threadIdx.x < n_mels) {
+    if ((flags & STTFE_KALDI_F64) && (int)threadIdx.x < n_mels) {       // precomputed by kaldi_stats_seq_kernel
+        const float* stf = reinterpret_cast<const float*>(st);
+        s_mean[threadIdx.x] = stf[threadIdx.x];
+        s_std[threadIdx.x] = stf[n_mels + threadIdx.x];
+    } else if ((int)threadIdx.x < n_mels) {
         const double inv_n = T > 0 ? 1.0 / (double)T : 0.0;
         const double mean = st[threadIdx.x] * inv_n;
         double var = st[n_mels + threadIdx.x] * inv_n - mean * mean;
@@ -456,6 +733,7 @@ extern "C" int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, 
                                       const int32_t* mask_tbl, int n_masks,
                                       void* workspace, size_t workspace_bytes, void* stream_) {
     if (batch < 0 || n_mels < 1 || n_mels > 128 || t_max < 0 || n_masks < 0 || n_masks > 8) return STTFE_E_INVALID_ARG;
+    if (flags & ~(STTFE_KALDI_NO_CMVN | STTFE_KALDI_F64)) return STTFE_E_INVALID_ARG;
     if (attn_mask && attn_mask_bytes != 4 && attn_mask_bytes != 8) return STTFE_E_INVALID_ARG;
     if (batch == 0 || t_max == 0) return STTFE_OK;
     if (!pcm || !offsets || !lengths || !dev_tables || !out || !workspace) return STTFE_E_INVALID_ARG;
@@ -497,11 +775,18 @@ extern "C" int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, 
     unsigned* ticket = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + need - 256);
     {
         ScopedTiming t(kTimeKaldiFbank, stream);
-        hipLaunchKernelGGL(kaldi_fbank_kernel, dim3(grid), dim3(kaldi::kThreads), 0, stream, pcm, offsets,
-                           lengths, n_mels, t_max, max_frames, tab, out, stats, tiles_per_block, n_runs, n_items, ticket);
+        if (flags & STTFE_KALDI_F64)
+            hipLaunchKernelGGL(kaldi_fbank_kernel<true>, dim3(grid), dim3(kaldi::kThreads), 0, stream, pcm, offsets,
+                               lengths, n_mels, t_max, max_frames, tab, out, stats, tiles_per_block, n_runs, n_items, ticket);
+        else
+            hipLaunchKernelGGL(kaldi_fbank_kernel<false>, dim3(grid), dim3(kaldi::kThreads), 0, stream, pcm, offsets,
+                               lengths, n_mels, t_max, max_frames, tab, out, stats, tiles_per_block, n_runs, n_items, ticket);
     }
     {
         ScopedTiming t(kTimeKaldiCmvn, stream);
+        if ((flags & STTFE_KALDI_F64) && !(flags & STTFE_KALDI_NO_CMVN))
+            hipLaunchKernelGGL(kaldi_stats_seq_kernel, dim3((batch * n_mels + 63) / 64), dim3(64), 0, stream, out, lengths,
+                               reinterpret_cast<float*>(workspace), batch, n_mels, t_max, max_frames);
         int cx = (t_max * n_mels + 255) / 256;
         if (cx > 64) cx = 64;
         hipLaunchKernelGGL(kaldi_cmvn_kernel, dim3(cx, batch), dim3(256), 0, stream, out, lengths, stats, n_mels,

@@ -54,14 +54,19 @@ void whisper_mel_bank(int n_mels, std::vector<float>& dense) {
     }
 }
 
-void kaldi_mel_bank(int n_mels, std::vector<float>& dense) {
+static void kaldi_mel_bank_f64(int n_mels, std::vector<double>& w) {
     const int n_bins = 257;
-    std::vector<double> pts(n_mels + 2), bins(n_bins), w;
+    std::vector<double> pts(n_mels + 2), bins(n_bins);
     const double m0 = hz_to_mel_kaldi(20.0), m1 = hz_to_mel_kaldi(8000.0);
     for (int i = 0; i < n_mels + 2; ++i) pts[i] = m0 + (m1 - m0) * (double)i / (double)(n_mels + 1);
     const double bin_width = 16000.0 / ((n_bins - 1) * 2);
     for (int k = 0; k < n_bins; ++k) bins[k] = hz_to_mel_kaldi(bin_width * k);
     triangular_bank(bins, pts, n_mels, w);
+}
+
+void kaldi_mel_bank(int n_mels, std::vector<float>& dense) {
+    std::vector<double> w;
+    kaldi_mel_bank_f64(n_mels, w);
     dense.resize(w.size());
     for (size_t i = 0; i < w.size(); ++i) dense[i] = (float)w[i];
 }
@@ -232,9 +237,49 @@ static int kaldi_tables(int n_mels, std::vector<unsigned char>& blob) {
             h.twiddle[2 * (32 * k1 + n2)] = (float)std::cos(2.0 * M_PI * m / 512.0);
             h.twiddle[2 * (32 * k1 + n2) + 1] = (float)(-std::sin(2.0 * M_PI * m / 512.0));
         }
-    blob.resize(sizeof(h) + afrag.size() * sizeof(float));
+    // float64 section (STTFE_KALDI_F64): Povey window and W_512^m = (cos, -sin)(2 pi m / 512), 8-byte aligned behind afrag
+    const size_t f64_off = (sizeof(h) + afrag.size() * sizeof(float) + 7) & ~(size_t)7;
+    std::vector<double> t64(400 + 2 * 512);
+    for (int i = 0; i < 400; ++i) t64[i] = std::pow(0.5 - 0.5 * std::cos(2.0 * M_PI * i / 399.0), 0.85);
+    for (int m = 0; m < 512; ++m) {
+        // exact values on the axes and diagonals; elsewhere long-double evaluation rounded once
+        const long double a = 2.0L * 3.14159265358979323846264338327950288L * (long double)m / 512.0L;
+        t64[400 + 2 * m] = (double)cosl(a);
+        t64[400 + 2 * m + 1] = (double)(-sinl(a));
+    }
+    t64[400 + 2 * 128] = 0.0;       // cos(pi / 2)
+    t64[400 + 2 * 384] = 0.0;       // cos(3 pi / 2)
+    t64[400 + 2 * 256 + 1] = 0.0;   // -sin(pi)
+    t64[400 + 1] = 0.0;             // -sin(0): +0.0
+    // the float64 mel bank as per-bin bands: {first bin, bins, offset of the first weight, 0} per mel bin (two doubles'
+    // worth of int32), then the weights themselves times 2^28 (see above; exact)
+    {
+        std::vector<double> w64;
+        kaldi_mel_bank_f64(n_mels, w64);
+        std::vector<int32_t> band(4 * (size_t)n_mels, 0);
+        std::vector<double> wts;
+        for (int m = 0; m < n_mels; ++m) {
+            int lo = 257, hi = -1;
+            for (int k = 0; k < 257; ++k)
+                if (w64[(size_t)m * 257 + k] != 0.0) {
+                    lo = std::min(lo, k);
+                    hi = std::max(hi, k);
+                }
+            band[4 * m] = hi >= lo ? lo : 0;
+            band[4 * m + 1] = hi >= lo ? hi - lo + 1 : 0;
+            band[4 * m + 2] = (int32_t)wts.size();
+            for (int k = lo; k <= hi; ++k) wts.push_back(w64[(size_t)m * 257 + k] * 268435456.0);
+        }
+        h.reserved = (int32_t)wts.size();          // number of float64 band weights (<= 2 per FFT bin)
+        const size_t base = t64.size();
+        t64.resize(base + 2 * (size_t)n_mels + wts.size());
+        std::memcpy(&t64[base], band.data(), band.size() * sizeof(int32_t));
+        std::memcpy(&t64[base + 2 * (size_t)n_mels], wts.data(), wts.size() * sizeof(double));
+    }
+    blob.assign(f64_off + t64.size() * sizeof(double), 0);
     std::memcpy(blob.data(), &h, sizeof(h));
     std::memcpy(blob.data() + sizeof(h), afrag.data(), afrag.size() * sizeof(float));
+    std::memcpy(blob.data() + f64_off, t64.data(), t64.size() * sizeof(double));
     return STTFE_OK;
 }
 

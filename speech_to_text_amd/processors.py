@@ -268,20 +268,25 @@ class HipSpeech2TextFeatureExtractor:
 
     def __init__(self, feature_size: int = 80, sampling_rate: int = 16000, num_mel_bins: int = 80,
                  padding_value: float = 0.0, do_ceptral_normalize: bool = True, normalize_means: bool = True,
-                 normalize_vars: bool = True, device: Optional[Union[str, torch.device]] = None, **kwargs):
+                 normalize_vars: bool = True, device: Optional[Union[str, torch.device]] = None,
+                 stft_precision: str = "float64", **kwargs):
         if sampling_rate != 16000:
             raise ValueError("the HIP kernels implement sampling_rate=16000")
-        if not (do_ceptral_normalize and normalize_means and normalize_vars):
-            raise ValueError("the HIP kernel always applies utterance CMVN (means and variances)")
+        if do_ceptral_normalize and not (normalize_means and normalize_vars):
+            raise ValueError("the HIP CMVN pass normalises means and variances together (the reference's configuration)")
         if not 1 <= num_mel_bins <= 128:
             raise ValueError("num_mel_bins must be in [1, 128]")
+        if stft_precision not in ("float64", "float32"):
+            raise ValueError("stft_precision must be 'float64' (HF NumPy-path arithmetic, the default) or 'float32' "
+                             "(torchaudio-Kaldi-path arithmetic, faster)")
         self.feature_size = feature_size
         self.num_mel_bins = num_mel_bins
         self.sampling_rate = sampling_rate
         self.padding_value = padding_value
-        self.do_ceptral_normalize = True
+        self.do_ceptral_normalize = bool(do_ceptral_normalize)     # False: raw ln(mel), HF:...speech_to_text.py:256-262
         self.normalize_means = True
         self.normalize_vars = True
+        self.stft_precision = stft_precision
         self.return_attention_mask = True
         self.n_fft = 512
         self.hop_length = 160
@@ -326,8 +331,15 @@ class HipSpeech2TextFeatureExtractor:
 
     def extract(self, pcm: torch.Tensor, offsets: torch.Tensor, lengths: torch.Tensor, t_max: int,
                 max_frames: int = 0, mask_table: Optional[torch.Tensor] = None,
-                attention_dtype: torch.dtype = torch.int32, apply_cmvn: bool = True):
-        """Device-resident entry -> (features (B, t_max, M) f32, attention_mask (B, t_max))."""
+                attention_dtype: torch.dtype = torch.int32, apply_cmvn: Optional[bool] = None,
+                stft_precision: Optional[str] = None):
+        """Device-resident entry -> (features (B, t_max, M) f32, attention_mask (B, t_max)).
+
+        ``apply_cmvn`` defaults to the extractor's ``do_ceptral_normalize``; ``stft_precision`` to the extractor's
+        (``"float64"``: STTFE_KALDI_F64, max-abs <= 1e-4 vs the HF NumPy path; ``"float32"``: the faster kernel)."""
+        if apply_cmvn is None:
+            apply_cmvn = self.do_ceptral_normalize
+        flags = (0 if apply_cmvn else 1) | (2 if (stft_precision or self.stft_precision) == "float64" else 0)
         device = pcm.device
         B = int(offsets.shape[0])
         L = _lib.lib()
@@ -344,8 +356,7 @@ class HipSpeech2TextFeatureExtractor:
         stream = torch.cuda.current_stream(device).cuda_stream
         with torch.cuda.device(device):
             _lib.check(L.sttfe_kaldi_fbank_cmvn(_lib.ptr(pcm), _lib.ptr(offsets), _lib.ptr(lengths), B,
-                                                self.num_mel_bins, t_max, int(max_frames or 0),
-                                                0 if apply_cmvn else 1,
+                                                self.num_mel_bins, t_max, int(max_frames or 0), flags,
                                                 _lib.ptr(self._tables_on(device)), _lib.ptr(out), _lib.ptr(attn),
                                                 attn.element_size(), _lib.ptr(mask_table), n_masks,
                                                 _lib.ptr(ws), ws.numel(), ctypes.c_void_p(stream)),

@@ -1,23 +1,19 @@
 """GPU parity of the Speech2Text fbank + CMVN path (row K) through the C ABI: HIP vs oracle vs HF goldens.
 
-Tolerance (stated here, derived in DESIGN.md "Parity of row K"): the oracle / HF NumPy fallback
-computes the STFT in float64; the HIP kernel -- like torchaudio's Kaldi fbank, which is what the
-reference actually runs when torchaudio is installed (HF speech_to_text.py:113-121) -- computes in
-float32.  A float32 512-point STFT has a noise floor of ~1e-8 of the frame's strongest FFT bin in
-amplitude, so a mel bin whose power is r times the frame's peak bin power carries a relative error
-of ~2e-8 / sqrt(r).  Pre-emphasis plus the Povey window push the lowest mel bins of these synthetic
-chirp signals 70-90 dB below the peak, hence:
+Tolerance: BASELINE.json north_star -- max abs error <= 1e-4, flat, on every cell of the raw log-mel and of the
+CMVN output, against the HF goldens and against the float64 oracle.  That is the bar of the DEFAULT mode
+(``stft_precision="float64"``, STTFE_KALDI_F64): DC removal, pre-emphasis, window and the 512-point DFT in float64,
+spectra rounded to complex64 afterwards, which is the arithmetic of HF's NumPy path (HF:audio_utils.py:957-993).
 
-    |d ln mel|  <=  1e-4 + 8e-8 * sqrt(peak_bin_power_of_frame_pair / mel) (raw log-mel; frames 2k
-                                                   and 2k+1 share one packed complex FFT)
+The optional float32 mode (``stft_precision="float32"``; what torchaudio's Kaldi fbank computes when torchaudio is
+installed, HF speech_to_text.py:113-121 -- not runnable here, so unpinned) has a float32 STFT noise floor of ~1e-8 of
+the frame's strongest FFT bin in amplitude: a mel bin whose power is r times the frame's peak bin power carries a
+relative error of ~2e-8 / sqrt(r).  For that mode only, the tests use the element-wise bound
+
+    |d ln mel|  <=  1e-4 + 8e-8 * sqrt(peak_bin_power_of_frame_pair / mel)
     |d cmvn|    <=  (b + mean_t b) / std + |z| * rms_t(b) / std + 2e-5 (1 + |z|)
-                                                   (after z = (x - mean) / std, b = the raw bound:
-                                                   |d mean| <= mean_t b, |d std| <= rms_t b by the
-                                                   triangle inequality; last term = float32 rounding
-                                                   of the CMVN arithmetic on both sides)
 
-i.e. 1e-4 wherever the bin is within ~55 dB of the frame peak, looser only below.  The bound is
-checked element by element against the float64 oracle.
+i.e. 1e-4 wherever the bin is within ~55 dB of the frame peak, looser only below.
 """
 import numpy as np
 import pytest
@@ -33,7 +29,15 @@ TOL = 1e-4
 @pytest.fixture(scope="module")
 def fe():
     from speech_to_text_amd.processors import HipSpeech2TextFeatureExtractor
-    return HipSpeech2TextFeatureExtractor(device="cuda:0")
+    fe = HipSpeech2TextFeatureExtractor(device="cuda:0")
+    assert fe.stft_precision == "float64"          # the default mode is the one held to the flat 1e-4
+    return fe
+
+
+@pytest.fixture(scope="module")
+def fe32():
+    from speech_to_text_amd.processors import HipSpeech2TextFeatureExtractor
+    return HipSpeech2TextFeatureExtractor(device="cuda:0", stft_precision="float32")
 
 
 def test_mel_bank_matches_oracle(fe):
@@ -64,7 +68,8 @@ def cmvn_bound(bound, raw_ref):
 
 
 def check_clip(fe, clip, exp_cmvn, max_length=None):
-    """HIP vs oracle for one clip: raw log-mel and CMVN output, both against the stated bounds."""
+    """HIP vs oracle / golden for one clip: raw log-mel and CMVN output.  float64 mode: flat 1e-4; float32 mode: the
+    element-wise bounds of the module docstring."""
     from oracle.kaldi import kaldi_fbank
     from speech_to_text_amd.processors import pack_clips
     raw_ref = kaldi_fbank(clip).astype(np.float64)
@@ -73,17 +78,23 @@ def check_clip(fe, clip, exp_cmvn, max_length=None):
     T = raw_ref.shape[0]
     pcm, off, ln = pack_clips([clip], torch.device("cuda:0"))
     raw, _ = fe.extract(pcm, off, ln, T, max_frames=max_length or 0, apply_cmvn=False)
-    bound = raw_bound(clip, raw_ref)
     d_raw = np.abs(raw[0].cpu().numpy() - raw_ref)
-    assert (d_raw <= bound).all(), float((d_raw / bound).max())
     out, _ = fe.extract(pcm, off, ln, T, max_frames=max_length or 0)
     d = np.abs(out[0].cpu().numpy() - exp_cmvn)
-    cb = cmvn_bound(bound, raw_ref)
-    assert (d <= cb).all(), float((d / cb).max())
+    if fe.stft_precision == "float64":
+        assert float(d_raw.max()) <= TOL, float(d_raw.max())
+        assert float(d.max()) <= TOL, float(d.max())
+    else:
+        bound = raw_bound(clip, raw_ref)
+        assert (d_raw <= bound).all(), float((d_raw / bound).max())
+        cb = cmvn_bound(bound, raw_ref)
+        assert (d <= cb).all(), float((d / cb).max())
     return float(d_raw.max()), float(d.max()), float(np.median(d))
 
 
-def test_matches_hf_goldens(fe):
+@pytest.mark.parametrize("mode", ["float64", "float32"])
+def test_matches_hf_goldens(mode, fe, fe32):
+    fe = fe if mode == "float64" else fe32
     z = load_golden("s2t_80.npz")
     names = sorted({k.split("__")[0] for k in z.files if k.endswith("__pcm")})
     for name in names:
@@ -92,38 +103,47 @@ def test_matches_hf_goldens(fe):
         assert o.input_features[0].shape == exp.shape, name
         assert o.attention_mask.dtype == torch.int32
         assert np.array_equal(o.attention_mask[0].cpu().numpy(), z[f"{name}__mask"])
+        if mode == "float64":
+            err = float(np.abs(o.input_features[0].cpu().numpy() - exp).max())
+            assert err <= TOL, (name, err)
         stats = check_clip(fe, z[f"{name}__pcm"], exp)
-        print(name, "max |d raw| %.2e  max |d cmvn| %.2e  median %.2e" % stats)
+        print(mode, name, "max |d raw| %.2e  max |d cmvn| %.2e  median %.2e" % stats)
     o = fe(z["k2_2p5s_odd__pcm"], sampling_rate=16000, truncation=True, max_length=100)
     assert o.input_features.shape == (1, 100, 80)
     assert np.array_equal(o.attention_mask[0].cpu().numpy(), z["k2_trunc100__mask"])
     check_clip(fe, z["k2_2p5s_odd__pcm"], z["k2_trunc100__feat"], max_length=100)
 
 
-def test_error_distribution(fe):
-    """How much of the output the plain 1e-4 covers: the looser part of the bound only applies to bins
-    far below the frame peak.  On these signals >= 95 % of the raw log-mel values and >= 90 % of the
-    CMVN outputs are within 1e-4 of the float64 oracle, and the median error is below 1e-5."""
+def test_error_distribution(fe, fe32):
+    """float64 mode: every raw log-mel value and every CMVN output within 1e-4 of the float64 oracle.  float32 mode:
+    the looser part of its bound only applies to bins far below the frame peak -- >= 95 % of the raw values and
+    >= 90 % of the CMVN outputs within 1e-4, median error below 1e-5."""
     from oracle.kaldi import kaldi_fbank, speech2text_features
     from speech_to_text_amd.processors import pack_clips
     clips = synth_batch(2002, [48000, 80000, 33333])
     pcm, off, ln = pack_clips(list(clips), torch.device("cuda:0"))
-    raw, _ = fe.extract(pcm, off, ln, 498, apply_cmvn=False)
-    raw = raw.cpu().numpy()
-    got = fe(clips, sampling_rate=16000).input_features.cpu().numpy()
     exp, _, tl = speech2text_features(clips)
-    d_raw = np.concatenate([np.abs(raw[i, :n] - kaldi_fbank(clips[i])).ravel() for i, n in enumerate(tl)])
-    d_out = np.concatenate([np.abs(got[i, :n] - exp[i, :n]).ravel() for i, n in enumerate(tl)])
-    print("raw: median %.1e p99 %.1e max %.1e within1e-4 %.4f | cmvn: median %.1e p99 %.1e max %.1e within1e-4 %.4f" % (
-        np.median(d_raw), np.percentile(d_raw, 99), d_raw.max(), (d_raw <= TOL).mean(),
-        np.median(d_out), np.percentile(d_out, 99), d_out.max(), (d_out <= TOL).mean()))
-    assert (d_raw <= TOL).mean() >= 0.95 and np.median(d_raw) <= 1e-5
-    assert (d_out <= TOL).mean() >= 0.90 and np.median(d_out) <= 2e-5
+    for f in (fe, fe32):
+        raw, _ = f.extract(pcm, off, ln, 498, apply_cmvn=False)
+        raw = raw.cpu().numpy()
+        got = f(clips, sampling_rate=16000).input_features.cpu().numpy()
+        d_raw = np.concatenate([np.abs(raw[i, :n] - kaldi_fbank(clips[i])).ravel() for i, n in enumerate(tl)])
+        d_out = np.concatenate([np.abs(got[i, :n] - exp[i, :n]).ravel() for i, n in enumerate(tl)])
+        print(f.stft_precision, "raw: median %.1e p99 %.1e max %.1e within1e-4 %.4f | cmvn: median %.1e p99 %.1e max %.1e "
+              "within1e-4 %.4f" % (np.median(d_raw), np.percentile(d_raw, 99), d_raw.max(), (d_raw <= TOL).mean(),
+                                   np.median(d_out), np.percentile(d_out, 99), d_out.max(), (d_out <= TOL).mean()))
+        if f.stft_precision == "float64":
+            assert d_raw.max() <= TOL and d_out.max() <= TOL
+        else:
+            assert (d_raw <= TOL).mean() >= 0.95 and np.median(d_raw) <= 1e-5
+            assert (d_out <= TOL).mean() >= 0.90 and np.median(d_out) <= 2e-5
 
 
-def test_batch_dynamic_padding_vs_oracle(fe):
+@pytest.mark.parametrize("mode", ["float64", "float32"])
+def test_batch_dynamic_padding_vs_oracle(mode, fe, fe32):
     """BASELINE config 2 shape at a size the oracle finishes in seconds: ragged 2-10 s clips."""
-    from oracle.kaldi import speech2text_features
+    from oracle.kaldi import kaldi_fbank, speech2text_features
+    fe = fe if mode == "float64" else fe32
     rng = np.random.default_rng(102)
     lengths = rng.integers(32000, 160001, size=24).tolist() + [400, 559, 560, 16000, 399, 100]
     clips = synth_batch(102, lengths)
@@ -132,14 +152,30 @@ def test_batch_dynamic_padding_vs_oracle(fe):
     got = o.input_features.cpu().numpy()
     assert got.shape == exp.shape
     assert np.array_equal(o.attention_mask.cpu().numpy(), mask)
-    from oracle.kaldi import kaldi_fbank
     for i, n in enumerate(tl):
         assert np.all(got[i, n:] == 0)
         if n >= 8:
-            raw_ref = kaldi_fbank(clips[i]).astype(np.float64)
-            cb = cmvn_bound(raw_bound(clips[i], raw_ref), raw_ref)
             d = np.abs(got[i, :n] - exp[i, :n])
-            assert (d <= cb).all(), (i, n, float((d / cb).max()))
+            if mode == "float64":
+                assert float(d.max()) <= TOL, (i, n, float(d.max()))
+            else:
+                raw_ref = kaldi_fbank(clips[i]).astype(np.float64)
+                cb = cmvn_bound(raw_bound(clips[i], raw_ref), raw_ref)
+                assert (d <= cb).all(), (i, n, float((d / cb).max()))
+
+
+def test_raw_fbank_without_cmvn_and_modes_agree(fe, fe32):
+    """do_ceptral_normalize=False returns ln(mel) itself (HF:...speech_to_text.py:256-262 skip the normalisation);
+    the two STFT precisions agree to the float32 mode's noise floor."""
+    from oracle.kaldi import kaldi_fbank
+    from speech_to_text_amd.processors import HipSpeech2TextFeatureExtractor
+    clip = synth_batch(31, [24000])[0]
+    raw_fe = HipSpeech2TextFeatureExtractor(device="cuda:0", do_ceptral_normalize=False)
+    got = raw_fe(clip, sampling_rate=16000).input_features[0].cpu().numpy()
+    assert float(np.abs(got - kaldi_fbank(clip)).max()) <= TOL
+    a = fe(clip, sampling_rate=16000).input_features
+    b = fe32(clip, sampling_rate=16000).input_features
+    assert float((a - b).abs().median()) <= 2e-5
 
 
 def test_specaugment_masks_and_int64_mask(fe):
