@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: Whisper 80-mel log-mel front-end on full 30 s clips (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks, one per GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (ranks from a launcher)
 
 One process per GPU.  A "step" = one pass of the hot path over one batch of synthetic clips that already
 sit in HBM.  Clips are sharded by rank (weak scaling: every rank processes its own batch; no collective
@@ -98,6 +98,100 @@ def profile_traffic(workload: str, clips_per_launch: float):
     return None
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh processes (one per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, the same command line), relay rank 0's JSON line, return the worst
+    exit code.  The parent never touches the GPU and never replaces itself; children are stopped by PID."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    worst = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0:
+                worst = worst or rc
+                for q in pending:               # a dead rank leaves the others waiting at a barrier: stop them
+                    procs[q].terminate()
+        time.sleep(0.05)
+    out = procs[0].stdout.read() if procs[0].stdout else ""
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return worst
+
+
+def run_stub(args, world: int, rank: int) -> None:
+    """The benchmark's multi-rank control flow with a host-only step (STTFE_BENCH_STUB=1, gloo)."""
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    audio_seconds = 100.0 * (rank + 1)            # rank-dependent, so that a SUM that misses a rank shows
+    step = lambda: time.sleep(0.002 * (rank + 1))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    barrier()
+    for _ in range(args.warmup):
+        step()
+    t_settle = time.perf_counter()
+    flag = torch.zeros(1, dtype=torch.int32)
+    settle_rounds = 0
+    while True:
+        done = time.perf_counter() - t_settle >= min(args.settle_seconds, 0.05) * (rank + 1)
+        if dist is not None:
+            flag.fill_(1 if done else 0)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            done = bool(flag.item())
+        if done:
+            break
+        step()
+        settle_rounds += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    audio_total = audio_seconds
+    rounds = torch.tensor([settle_rounds], dtype=torch.int64)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        a = torch.tensor([audio_seconds], dtype=torch.float64)
+        dist.all_reduce(a, op=dist.ReduceOp.SUM)
+        audio_total = float(a.item())
+        lo, hi = rounds.clone(), rounds.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        rounds = torch.stack([lo, hi]).reshape(-1)
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": audio_total * args.steps / elapsed, "unit": "audio-s/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "audio_total": audio_total, "settle_rounds": [int(v) for v in rounds.tolist()]}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,10 +219,15 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        # not under a launcher: this process (which has not touched the GPU) starts the N ranks itself
+        raise SystemExit(spawn_ranks(args.gpus))
     # STTFE_BENCH_REHEARSE=1: rehearsal of the N > 1 code path on a one-GPU box -- the ranks share GPU 0 and the
     # barrier / reductions go over gloo (RCCL refuses two ranks on one device).  Never set for a real measurement.
+    # STTFE_BENCH_STUB=1: the same control flow (barriers, lock-step settle, MAX / SUM reductions, one JSON line) with
+    # no GPU at all -- a step is a short host sleep -- so that tests/test_bench_ranks_cpu.py can cover N > 1 on CPU.
+    stub = os.environ.get("STTFE_BENCH_STUB") == "1"
+    if stub:
+        return run_stub(args, world, rank)
     rehearse = os.environ.get("STTFE_BENCH_REHEARSE") == "1"
     dev_index = local_rank % max(torch.cuda.device_count(), 1) if rehearse else local_rank
     torch.cuda.set_device(dev_index)
