@@ -87,6 +87,20 @@ int sttfe_whisper_logmel_scaled(const float* pcm, const int64_t* offsets, const 
                                 float* out, const int32_t* mask_tbl, int n_masks, const float* clip_scale,
                                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same extractor with the semantics of the reference's own TorchWhisperFeatureExtractor (src/processors.py:148-246;
+ * HF mel bank), which differ from HF's in which frames exist and which count for the clamp:
+ *   variable_length = 0 (padding=True, src/processors.py:180-221): pad / truncate to 30 s, per-clip max over all 3001
+ *       STFT frames, THEN crop to 3000 (HF drops the last frame before the max); n_frames must be 3000;
+ *   variable_length = 1 (padding=False, :222-239): no padding -- reflect at the clip's own end, 1 + lengths[b] / 160
+ *       frames, per-clip max over them, cropped to 3000; out is [batch][n_mels][n_frames] with n_frames >= the longest
+ *       clip's (cropped) frame count and a multiple of 4; frames past a clip's own are padding_value.  Clips need more
+ *       than 200 samples (torch.stft's reflect padding raises below that; here such clips give unspecified values) and
+ *       at most 483 680 samples count (3024 frames; the reference has no limit). */
+int sttfe_whisper_logmel_torch(const float* pcm, const int64_t* offsets, const int32_t* lengths,
+                               int batch, int n_mels, int n_frames, const void* dev_tables,
+                               float* out, const int32_t* mask_tbl, int n_masks, int variable_length,
+                               float padding_value, void* workspace, size_t workspace_bytes, void* stream);
+
 /* sttfe_whisper_logmel for callers that cannot allocate.  No counterpart in the reference: it is for code under HIP
  * graph capture, tight serving loops and harnesses that forbid hipMalloc, which cannot size and provide the
  * `workspace` argument above.  Same inputs, outputs and results as sttfe_whisper_logmel; the workspace (per-clip max

@@ -53,6 +53,12 @@ constexpr int kFramesPerWave = 12;            // two passes of 3 pairs
 constexpr int kHop = 160;
 constexpr int kNfft = 400;
 constexpr int kMaxSamples = 480000;           // 30 s at 16 kHz (HF:...whisper.py:91)
+constexpr int kVarMaxSamples = 160 * 3023;    // variable-length mode: clips of up to 3024 frames (63 tiles)
+// Which frames count and how clips end (reference src/processors.py:180-239 differs from HF in both):
+constexpr int kModeHF = 0;          // pad / truncate to 30 s, last frame dropped before the per-clip max (HF)
+constexpr int kModeTorchPadded = 1; // pad / truncate to 30 s, per-clip max over all 3001 frames, then crop (:206-219)
+constexpr int kModeTorchVarlen = 2; // no padding: reflect at the clip's own end, 1 + n / 160 frames, max over them,
+                                    // crop to 3000, frames past the clip's own <- padding_value (:222-239)
 constexpr int kMaxTiles = 63;                 // ceil(3000 / 48)
 constexpr int kKeysPerClip = 64;              // workspace: [0] = max key, [1 + t] = ~min key of tile t
 constexpr int kRowStride = 22;                // complex units, [k1][n2] rows: 176 B, so a row reads as 10 x b128
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     const int32_t* __restrict__ lengths, int n_mels, int n_frames,
     const WhisperTablesHeader* __restrict__ tab, float* __restrict__ out,
     unsigned* __restrict__ keys, const int32_t* __restrict__ mask_tbl, int n_masks, int tiles_per_block,
-    int batch, unsigned* __restrict__ ticket, const float* __restrict__ clip_scale) {
+    int batch, unsigned* __restrict__ ticket, const float* __restrict__ clip_scale, int mode, float pad_value) {
     using namespace wh;
     __shared__ __attribute__((aligned(16))) float smem[kLdsFloats];
 
@@ -167,9 +173,14 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     // atomic, the length / offset of the next item and its first PCM tile are all in flight under useful work.
     // Every workgroup leaves its loop after at most n_items tickets; all threads of a workgroup take the same path.
     const int n_tiles = (n_frames + kTileFrames - 1) / kTileFrames;
-    auto clamp_len = [](int n) { return n < 0 ? 0 : (n > kMaxSamples ? kMaxSamples : n); };
-    // first tile that lies entirely in the zero padding (those are constant: kernel 2 fills them)
-    auto first_pad_tile_of = [](int n_valid) { return (n_valid + kNfft / 2 + kHop * kTileFrames - 1) / (kHop * kTileFrames); };
+    const int len_cap = mode == kModeTorchVarlen ? kVarMaxSamples : kMaxSamples;
+    auto clamp_len = [len_cap](int n) { return n < 0 ? 0 : (n > len_cap ? len_cap : n); };
+    // first tile that lies entirely in the padding (those are constant: kernel 2 fills them): past the last frame that
+    // touches a valid sample (zero padding to 30 s) or, in variable-length mode, past the clip's own 1 + n / 160 frames
+    auto first_pad_tile_of = [mode](int n_valid) {
+        return mode == kModeTorchVarlen ? (1 + n_valid / kHop + kTileFrames - 1) / kTileFrames
+                                        : (n_valid + kNfft / 2 + kHop * kTileFrames - 1) / (kHop * kTileFrames);
+    };
     unsigned my_ticket = 0;
     if (tid == 0) my_ticket = atomicAdd(ticket, 1u);               // -> the workgroup's second item
     // longest and shortest clip of the batch (every workgroup computes the same values; skipped for very large batches)
@@ -239,9 +250,10 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 #pragma unroll
             for (int m = 0; m < 28; ++m) {
                 int idx = base + 20 * m;
+                const int lim = mode == kModeTorchVarlen ? n_valid : kMaxSamples;
                 idx = idx < 0 ? -idx : idx;                                       // reflect padding (center=True) ...
-                idx = idx >= kMaxSamples ? 2 * (kMaxSamples - 1) - idx : idx;     // ... of the 30 s buffer
-                r[m] = (idx < n_valid) ? x[idx] : 0.0f;                           // zero padding to 30 s
+                idx = idx >= lim ? 2 * (lim - 1) - idx : idx;                     // ... of the 30 s buffer / of the clip
+                r[m] = (idx >= 0 && idx < n_valid) ? x[idx] : 0.0f;               // zero padding to 30 s
             }
         }
     };
@@ -396,6 +408,8 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
       }
       const int tile_begin = run * tiles_per_block;
       const int tile_end = min(min(tile_begin + tiles_per_block, n_tiles), first_pad_tile_of(n_valid));
+      // frames that count for the per-clip maximum (and hold data rather than padding_value)
+      const int key_frames = mode == kModeTorchVarlen ? 1 + n_valid / kHop : (mode == kModeTorchPadded ? n_frames + 1 : n_frames);
       if (tile_begin < tile_end) {
       float* __restrict__ out_clip = out + (size_t)clip * n_mels * n_frames;
       // SpecAugment: mel-axis masks as two 64-bit words for the clip; time-axis masks per tile
@@ -523,7 +537,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
                 mv[r] = fmaxf(acc[r], mel_floor);
                 yv[r] = fmaf(__log2f(mv[r]), 0.25f * 0.30102999566398120f, y_bias);
             }
-            const bool whole = (mt * 16 + 16 <= n_mels) && (t0 + ft * 16 + 16 <= n_frames);    // wave-uniform
+            const bool whole = (mt * 16 + 16 <= n_mels) && (t0 + ft * 16 + 16 <= min(n_frames, key_frames));    // wave-uniform
             if (whole && nm == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -534,12 +548,17 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
             } else {
                 const bool tmasked = (tmask >> fl) & 1ull;
                 const unsigned mbits = (unsigned)((mel0 < 64 ? melmask_lo >> mel0 : melmask_hi >> (mel0 - 64)) & 15ull);
+                const bool counted = t0 + fl < key_frames, stored = t0 + fl < n_frames;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (mel0 + r < n_mels && t0 + fl < n_frames) {
-                        run_max = fmaxf(run_max, mv[r]);
-                        tile_min = fminf(tile_min, mv[r]);
-                        out_clip[o0 + (unsigned)(r * n_frames)] = (tmasked || ((mbits >> r) & 1u)) ? 0.0f : yv[r];
+                    if (mel0 + r < n_mels) {
+                        if (counted) {
+                            run_max = fmaxf(run_max, mv[r]);
+                            tile_min = fminf(tile_min, mv[r]);
+                        }
+                        if (stored)
+                            out_clip[o0 + (unsigned)(r * n_frames)] =
+                                (tmasked || ((mbits >> r) & 1u)) ? 0.0f : (counted ? yv[r] : pad_value);
                     }
                 }
             }
@@ -587,7 +606,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     float* __restrict__ out, const int32_t* __restrict__ lengths, const unsigned* __restrict__ keys,
     int n_mels, int n_frames, const int32_t* __restrict__ mask_tbl, int n_masks,
-    const float* __restrict__ clip_scale) {
+    const float* __restrict__ clip_scale, int mode, float pad_value) {
     using namespace wh;
     const int clip = blockIdx.y;
     const int row0 = blockIdx.x, row_step = gridDim.x;
@@ -602,17 +621,22 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     unsigned kmin_raw = 0xffffffffu;
     if (threadIdx.x < kKeysPerClip - 1) kmin_raw = keys[(size_t)clip * kKeysPerClip + 1 + threadIdx.x];
     if ((int)threadIdx.x < 3 * nm) s_masks[threadIdx.x] = mask_tbl[(size_t)clip * n_masks * 3 + threadIdx.x];
-    n_valid = n_valid < 0 ? 0 : (n_valid > kMaxSamples ? kMaxSamples : n_valid);
+    const int len_cap = mode == kModeTorchVarlen ? kVarMaxSamples : kMaxSamples;
+    n_valid = n_valid < 0 ? 0 : (n_valid > len_cap ? len_cap : n_valid);
     const int n_tiles = (n_frames + kTileFrames - 1) / kTileFrames;
-    const int first_pad_tile = min(n_tiles, (n_valid + kNfft / 2 + kHop * kTileFrames - 1) / (kHop * kTileFrames));
+    const int first_pad_tile = min(n_tiles, mode == kModeTorchVarlen
+                                                ? (1 + n_valid / kHop + kTileFrames - 1) / kTileFrames
+                                                : (n_valid + kNfft / 2 + kHop * kTileFrames - 1) / (kHop * kTileFrames));
     const int pad_frame = min(n_frames, first_pad_tile * kTileFrames);         // first frame of the constant region
+    const int key_frames = mode == kModeTorchVarlen ? 1 + n_valid / kHop : n_frames;   // frames that hold data
     // scaled clips (see kernel 1): keys are log10 of the unscaled energies, stored values carry the bias c / 4 with
     // c = 2 log10(s); the zero padding is log10(1e-10) = -10 in the scaled domain, i.e. -10 - c in the keys' domain
     const float c_lg = clip_scale ? 2.0f * 0.30102999566398120f * __log2f(clip_scale[clip]) : 0.0f;
     const float lmax = kmax ? key_to_float(kmax) : -10.0f - c_lg; // no computed tile at all: the floor itself
     const float floor_lg = lmax - 8.0f;
     const float floor_y = (floor_lg + 4.0f) * 0.25f + 0.25f * c_lg;
-    const float pad_y = fmaxf((-10.0f + 4.0f) * 0.25f, floor_y);
+    // zero padding to 30 s: log10(1e-10) clamped like everything else; variable-length mode: the literal padding_value
+    const float pad_y = mode == kModeTorchVarlen ? pad_value : fmaxf((-10.0f + 4.0f) * 0.25f, floor_y);
 
     // tiles of the clip with something below the floor (n_tiles <= 63: one 64-bit word)
     if (threadIdx.x < 64) {
@@ -708,8 +732,8 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
             bool changed = false;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float y = fmaxf(v[i][c], floor_y);
                 const int fr = fr0[i] + c;
+                float y = fr < key_frames ? fmaxf(v[i][c], floor_y) : v[i][c];   // padding_value cells stay as they are
                 bool masked = mmasked;                             // masked cells of a computed tile already hold 0.0
                 for (int m = 0; m < nt; ++m) masked |= (fr >= ts[m] && fr < te[m]);
                 if (masked) y = 0.0f;
@@ -750,7 +774,8 @@ extern "C" int sttfe_set_whisper_tiles_per_block(int tiles) {
 static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const int32_t* lengths,
                                int batch, int n_mels, int n_frames, const void* dev_tables,
                                float* out, const int32_t* mask_tbl, int n_masks, const float* clip_scale,
-                               void* workspace, size_t workspace_bytes, void* stream_) {
+                               void* workspace, size_t workspace_bytes, void* stream_, int mode = wh::kModeHF,
+                               float pad_value = 0.0f) {
     if (batch < 0 || n_mels < 1 || n_mels > 128 || n_frames < 1 || (n_frames & 3) || n_masks < 0 || n_masks > 8)
         return STTFE_E_INVALID_ARG;
     if (batch == 0) return STTFE_OK;
@@ -796,7 +821,7 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
 #endif
         hipLaunchKernelGGL(whisper_stft_mel_kernel, dim3(grid), dim3(wh::kThreads), dyn_lds, stream,
                            pcm, offsets, lengths, n_mels, n_frames, tab, out, keys, mask_tbl, n_masks, tiles_per_block,
-                           batch, keys + (size_t)batch * wh::kKeysPerClip, clip_scale);
+                           batch, keys + (size_t)batch * wh::kKeysPerClip, clip_scale, mode, pad_value);
     }
     {
         ScopedTiming t(kTimeWhisperClamp, stream);
@@ -808,7 +833,7 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
         }();
         const int row_split = row_split_env ? row_split_env : (n_mels > 96 ? (n_mels + 3) / 4 : (n_mels + 4) / 5);
         hipLaunchKernelGGL(whisper_clamp_fill_kernel, dim3(row_split, batch), dim3(256), 0, stream, out, lengths, keys,
-                           n_mels, n_frames, mask_tbl, n_masks, clip_scale);
+                           n_mels, n_frames, mask_tbl, n_masks, clip_scale, mode, pad_value);
     }
     if (hip_failed(hipGetLastError(), "whisper kernel launch")) return STTFE_E_LAUNCH;
     return STTFE_OK;
@@ -820,6 +845,18 @@ extern "C" int sttfe_whisper_logmel(const float* pcm, const int64_t* offsets, co
                                     void* workspace, size_t workspace_bytes, void* stream) {
     return whisper_logmel_impl(pcm, offsets, lengths, batch, n_mels, n_frames, dev_tables, out, mask_tbl, n_masks,
                                nullptr, workspace, workspace_bytes, stream);
+}
+
+// TorchWhisperFeatureExtractor semantics (reference src/processors.py:180-239), see include/sttfe.h
+extern "C" int sttfe_whisper_logmel_torch(const float* pcm, const int64_t* offsets, const int32_t* lengths,
+                                          int batch, int n_mels, int n_frames, const void* dev_tables,
+                                          float* out, const int32_t* mask_tbl, int n_masks, int variable_length,
+                                          float padding_value, void* workspace, size_t workspace_bytes, void* stream) {
+    if (variable_length != 0 && variable_length != 1) return STTFE_E_INVALID_ARG;
+    if (!variable_length && n_frames != wh::kMaxSamples / wh::kHop) return STTFE_E_INVALID_ARG;   // 3001 frames -> 3000
+    return whisper_logmel_impl(pcm, offsets, lengths, batch, n_mels, n_frames, dev_tables, out, mask_tbl, n_masks,
+                               nullptr, workspace, workspace_bytes, stream,
+                               variable_length ? wh::kModeTorchVarlen : wh::kModeTorchPadded, padding_value);
 }
 
 // ---- the entry point that allocates nothing (no counterpart in the reference; include/sttfe.h) ----

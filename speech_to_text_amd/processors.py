@@ -239,9 +239,39 @@ class TorchWhisperFeatureExtractor(HipWhisperFeatureExtractor):
 
     Same constructor arguments and ``__call__(raw_speech, sampling_rate, return_tensors, padding)``;
     returns a ``SimpleNamespace(input_features=...)`` like the reference (src/processors.py:241-246)
-    and raises ``ValueError`` on a wrong sampling rate (src/processors.py:165-166).  Only the fixed
-    30-second form (``padding=True``) is implemented; numerics are HF's (slaney mel scale).
+    and raises ``ValueError`` on a wrong sampling rate (src/processors.py:165-166).  Both branches keep the
+    reference class's own semantics (``sttfe_whisper_logmel_torch``), which differ from HF's:
+
+    * ``padding=True`` (src/processors.py:180-221): pad / truncate to 30 s, per-clip max over all 3001 STFT frames,
+      then crop to 3000 (HF drops the last frame before taking the max);
+    * ``padding=False`` (:222-239): no padding -- reflect at the clip's own end, ``1 + n // 160`` frames, per-clip
+      max over them, crop to 3000, pad to the longest clip of the batch with ``padding_value``.
+
+    One deliberate difference: the mel bank is HF's (slaney scale), the parity target of this build, not the
+    HTK-scale bank of src/processors.py:75-83.  ``padding=False`` needs clips of more than 200 samples (torch.stft's
+    reflect padding raises below that, and so does this class) and of at most 483 680 samples (30.23 s).
     """
+
+    MAX_VARLEN_SAMPLES = 160 * 3023
+
+    def extract_torch(self, pcm: torch.Tensor, offsets: torch.Tensor, lengths: torch.Tensor, n_frames: int,
+                      variable_length: bool) -> torch.Tensor:
+        """Device-resident entry -> (B, M, n_frames) float32 with the reference class's semantics."""
+        device = pcm.device
+        B = int(offsets.shape[0])
+        L = _lib.lib()
+        out = torch.empty((B, self.feature_size, n_frames), dtype=torch.float32, device=device)
+        ws_bytes = ctypes.c_size_t()
+        _lib.check(L.sttfe_whisper_workspace_bytes(B, ctypes.byref(ws_bytes)))
+        ws = torch.empty(max(ws_bytes.value, 1), dtype=torch.uint8, device=device)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        with torch.cuda.device(device):
+            _lib.check(L.sttfe_whisper_logmel_torch(_lib.ptr(pcm), _lib.ptr(offsets), _lib.ptr(lengths), B,
+                                                    self.feature_size, n_frames, _lib.ptr(self._tables_on(device)),
+                                                    _lib.ptr(out), None, 0, 1 if variable_length else 0,
+                                                    ctypes.c_float(self.padding_value), _lib.ptr(ws), ws.numel(),
+                                                    ctypes.c_void_p(stream)), "sttfe_whisper_logmel_torch")
+        return out
 
     def __call__(self, raw_speech, sampling_rate: Optional[int] = None, return_tensors: Optional[str] = "pt",
                  padding: Optional[bool] = True):
@@ -249,10 +279,28 @@ class TorchWhisperFeatureExtractor(HipWhisperFeatureExtractor):
             sampling_rate = self.sampling_rate
         if sampling_rate != self.sampling_rate:
             raise ValueError(f"Expected sampling_rate={self.sampling_rate}, got {sampling_rate}. Resample beforehand.")
-        if not padding:
-            raise NotImplementedError("padding=False (variable-length output) is not implemented by the HIP extractor")
-        out = super().__call__(raw_speech, sampling_rate=sampling_rate, return_tensors=return_tensors)
-        return SimpleNamespace(input_features=out["input_features"])
+        clips = _as_clip_list(raw_speech)
+        device = self.device
+        if not clips:
+            feats = torch.empty((0, self.feature_size, self.nb_max_frames if padding else 0), dtype=torch.float32,
+                                device=device)
+        elif padding:
+            pcm, offsets, lengths = pack_clips(clips, device, self.n_samples + self.hop_length)
+            feats = self.extract_torch(pcm, offsets, lengths, self.nb_max_frames, False)
+        else:
+            lens = [int(c.shape[-1]) if torch.is_tensor(c) else int(np.asarray(c).reshape(-1).shape[0]) for c in clips]
+            if min(lens) <= self.n_fft // 2:
+                raise ValueError(f"padding=False needs clips longer than {self.n_fft // 2} samples (reflect padding of "
+                                 f"the STFT); got {min(lens)}")
+            if max(lens) > self.MAX_VARLEN_SAMPLES:
+                raise ValueError(f"padding=False handles clips of up to {self.MAX_VARLEN_SAMPLES} samples; got "
+                                 f"{max(lens)}: truncate to {self.chunk_length} s first")
+            frames = min(max(1 + n // self.hop_length for n in lens), self.expected_frames)
+            pcm, offsets, lengths = pack_clips(clips, device, self.MAX_VARLEN_SAMPLES)
+            feats = self.extract_torch(pcm, offsets, lengths, (frames + 3) // 4 * 4, True)[:, :, :frames]
+        if return_tensors != "pt":
+            feats = feats.detach().cpu().numpy()
+        return SimpleNamespace(input_features=feats)
 
 
 class HipSpeech2TextFeatureExtractor:
