@@ -39,6 +39,8 @@ extern "C" {
 
 #define STTFE_AXIS_FREQ 0
 #define STTFE_AXIS_TIME 1
+#define STTFE_MAX_MASKS 16         /* SpecAugment masks per clip (num_time_masks + num_freq_masks, src/config.py:43-44);
+                                      more than that: STTFE_E_INVALID_ARG */
 
 int sttfe_version(void);
 const char* sttfe_strerror(int code);

@@ -651,8 +651,8 @@ __global__ __launch_bounds__(256) void kaldi_cmvn_kernel(
     const int T = kaldi_num_frames(lengths[clip], max_frames, t_max);
     float* __restrict__ o = out + (size_t)clip * t_max * n_mels;
     const double* st = stats + (size_t)clip * 2 * n_mels;
-    int m_axis[8], m_s[8], m_e[8];
-    const int nm = mask_tbl ? (n_masks > 8 ? 8 : n_masks) : 0;
+    int m_axis[STTFE_MAX_MASKS], m_s[STTFE_MAX_MASKS], m_e[STTFE_MAX_MASKS];
+    const int nm = mask_tbl ? (n_masks > STTFE_MAX_MASKS ? STTFE_MAX_MASKS : n_masks) : 0;
     for (int i = 0; i < nm; ++i) {
         const int32_t* m = mask_tbl + ((size_t)clip * n_masks + i) * 3;
         m_axis[i] = m[0];
@@ -732,7 +732,7 @@ extern "C" int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, 
                                       const void* dev_tables, float* out, void* attn_mask, int attn_mask_bytes,
                                       const int32_t* mask_tbl, int n_masks,
                                       void* workspace, size_t workspace_bytes, void* stream_) {
-    if (batch < 0 || n_mels < 1 || n_mels > 128 || t_max < 0 || n_masks < 0 || n_masks > 8) return STTFE_E_INVALID_ARG;
+    if (batch < 0 || n_mels < 1 || n_mels > 128 || t_max < 0 || n_masks < 0 || n_masks > STTFE_MAX_MASKS) return STTFE_E_INVALID_ARG;
     if (flags & ~(STTFE_KALDI_NO_CMVN | STTFE_KALDI_F64)) return STTFE_E_INVALID_ARG;
     if (attn_mask && attn_mask_bytes != 4 && attn_mask_bytes != 8) return STTFE_E_INVALID_ARG;
     if (batch == 0 || t_max == 0) return STTFE_OK;

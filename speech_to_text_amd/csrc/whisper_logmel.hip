@@ -76,8 +76,8 @@ constexpr int kAfragOff = kTwOff + 20 * kTwStride;               // banded mel w
 constexpr int kMaxAfragFloats = 4608;                 // 53 (80 mels) / 56 (128 mels) k-steps x 64 lanes
 constexpr int kDescOff = kAfragOff + kMaxAfragFloats;     // per wave: 8 x {kstart, nsteps, aoff, mt | ft << 8}, then the unit counts
 constexpr int kTicketOff = kDescOff + kWaves * kMaxUnitsPerWave * 4 + kWaves;    // 3 words: work-item hand-over slots
-constexpr int kMaskOff = kTicketOff + 4;              // the current clip's SpecAugment masks: 8 x {axis, start, end}
-constexpr int kLdsFloats = kMaskOff + 24;   // 62032 B -> 2 workgroups per CU
+constexpr int kMaskOff = kTicketOff + 4;              // the current clip's SpecAugment masks: STTFE_MAX_MASKS x {axis, start, end}
+constexpr int kLdsFloats = kMaskOff + 3 * STTFE_MAX_MASKS;   // ~65 KB -> 2 workgroups per CU
 }  // namespace wh
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     // the clip's mask table -> LDS): with four dependent round trips per workgroup this kernel was latency-bound
     // (0.10 ms for 32 k workgroups that find nothing to clamp).
     __shared__ unsigned long long s_flags;
-    __shared__ int32_t s_masks[24];
+    __shared__ int32_t s_masks[3 * STTFE_MAX_MASKS];
     const int nm = mask_tbl ? n_masks : 0;
     int n_valid = lengths[clip];
     const unsigned kmax = keys[(size_t)clip * kKeysPerClip];
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     const int32_t* cm = s_masks;
     const uint64_t melmask_lo = mask_bits(cm, nm, STTFE_AXIS_FREQ, 0, 64);
     const uint64_t melmask_hi = mask_bits(cm, nm, STTFE_AXIS_FREQ, 64, 64);
-    int ts[8], te[8], nt = 0;                                      // time-axis masks of the clip
+    int ts[STTFE_MAX_MASKS], te[STTFE_MAX_MASKS], nt = 0;          // time-axis masks of the clip
     for (int i = 0; i < nm; ++i)
         if (cm[3 * i] == STTFE_AXIS_TIME && cm[3 * i + 2] > cm[3 * i + 1]) {
             ts[nt] = cm[3 * i + 1];
@@ -776,7 +776,7 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
                                float* out, const int32_t* mask_tbl, int n_masks, const float* clip_scale,
                                void* workspace, size_t workspace_bytes, void* stream_, int mode = wh::kModeHF,
                                float pad_value = 0.0f) {
-    if (batch < 0 || n_mels < 1 || n_mels > 128 || n_frames < 1 || (n_frames & 3) || n_masks < 0 || n_masks > 8)
+    if (batch < 0 || n_mels < 1 || n_mels > 128 || n_frames < 1 || (n_frames & 3) || n_masks < 0 || n_masks > STTFE_MAX_MASKS)
         return STTFE_E_INVALID_ARG;
     if (batch == 0) return STTFE_OK;
     if (!pcm || !offsets || !lengths || !dev_tables || !out || !workspace) return STTFE_E_INVALID_ARG;

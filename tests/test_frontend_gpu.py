@@ -158,3 +158,37 @@ def test_feature_cache_round_trip_of_gpu_features(tmp_path):
     for i in range(len(lens)):
         assert ds[i]["id"] == i and ds[i]["text"] == f"t{i}"
         assert torch.equal(ds[i]["input_features"], direct[i].cpu()), i
+
+
+def test_more_masks_than_the_old_limit_and_the_error_path():
+    """num_time_masks / num_freq_masks are free config fields (src/config.py:43-44): 5 + 5 masks per clip work and stay
+    bit-exact; beyond STTFE_MAX_MASKS (16) the call fails loudly instead of dropping masks."""
+    from oracle.whisper import whisper_features
+    from speech_to_text_amd import _lib
+    clips = synth_batch(33, [48000, 80000, 16000])
+    samples = [{"audio": torch.from_numpy(c)[None, :], "text": "t"} for c in clips]
+
+    def front_for(nt, nf):
+        aug = AugmentationConfig(enabled=True, add_noise=False, speed_perturbation=False, pitch_shift=False,
+                                 volume_perturbation=False, fade_inout=False, spec_augment_probability=1.0,
+                                 num_time_masks=nt, num_freq_masks=nf)
+        cfg = DataConfig(processing_and_augmentation_device="cuda", augmentation=aug)
+        return cfg, GpuFrontEnd(cfg, "whisper", False, split="train", feature_size=80, device=DEV)
+
+    cfg, front = front_for(5, 5)
+    raw = AudioCollator(cfg, "whisper")(samples)
+    torch.manual_seed(7)
+    random.seed(7)
+    got = front(raw)["input_features"].cpu().numpy()
+    torch.manual_seed(7)
+    random.seed(7)
+    masks = [S.draw_clip_masks(80, 3000, probability=1.0, num_time_masks=5, num_freq_masks=5) for _ in clips]
+    assert all(len(m) == 10 for m in masks)
+    exp = whisper_features(clips, 80)
+    for b in range(3):
+        assert np.abs(got[b] - S.apply_masks(exp[b], masks[b])).max() <= 1e-4
+        for axis, s, t in masks[b]:
+            assert not (got[b][:, s:t] if axis == S.AXIS_TIME else got[b][s:t, :]).any()
+    cfg, front = front_for(9, 8)                                       # 17 masks per clip
+    with pytest.raises(_lib.SttfeError, match="invalid argument"):
+        front(AudioCollator(cfg, "whisper")(samples))
