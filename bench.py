@@ -402,7 +402,7 @@ def main():
     seen = ctypes.c_int()
     _lib.check(L.sttfe_timing_seen(kernel.encode(), ctypes.byref(seen)))
     launches = seen.value
-    others = {k: query(k) for k in (["whisper_clamp_mask"] if kernel == "whisper_stft_mel" else []) + extra_kernels}
+    others = {k: query(k) for k in (["whisper_clamp_fill"] if kernel == "whisper_stft_mel" else []) + extra_kernels}
     _lib.check(L.sttfe_timing_set_stride(1))
     _lib.check(L.sttfe_timing_enable(0))
 

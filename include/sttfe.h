@@ -33,7 +33,10 @@ extern "C" {
 #define STTFE_OK 0
 #define STTFE_E_INVALID_ARG (-1)   /* NULL pointer, negative size, unsupported n_mels ... */
 #define STTFE_E_WORKSPACE (-2)     /* workspace too small */
-#define STTFE_E_TABLES (-3)        /* tables blob does not match the call */
+#define STTFE_E_TABLES (-3)        /* tables blob does not match the call (host-side checks: *_tables_build with a
+                                      short buffer, resample plans).  A DEVICE tables blob built for another extractor
+                                      (wrong kind or n_mels) cannot be reported without synchronising: the feature
+                                      kernels check its header themselves and make every output element NaN. */
 #define STTFE_E_LAUNCH (-4)        /* HIP reported a launch error */
 #define STTFE_E_UNSUPPORTED (-5)   /* sampling-rate ratio / size outside what the kernels handle */
 
@@ -272,7 +275,7 @@ int sttfe_set_whisper_tiles_per_block(int tiles);
  * launch stream around every kernel launch (used by bench.py for the roofline figure).
  * sttfe_timing_enable(capacity) allocates `capacity` event pairs (0 disables and frees them);
  * sttfe_timing_query(name, ...) returns the summed duration and launch count of one kernel
- * ("whisper_stft_mel", "whisper_clamp_mask", "kaldi_fbank", "kaldi_cmvn", "resample_peak",
+ * ("whisper_stft_mel", "whisper_clamp_fill", "kaldi_fbank", "kaldi_cmvn", "resample_peak",
  * "normalize_trim", "waveform_augment", "pitch_shift") since the last enable/reset; it synchronises on the recorded events.
  */
 int sttfe_timing_enable(int capacity);

@@ -31,6 +31,8 @@
 
 namespace sttfe {
 
+int current_device_cus();      // whisper_logmel.hip
+
 namespace kaldi {
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
@@ -130,6 +132,7 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int item = blockIdx.x;
     if (item >= n_items) return;
+    if (tab->magic != kKaldiMagic || tab->n_mels != n_mels) return;      // the CMVN pass poisons the output
     // per-item state (set at the top of the item loop; the lambdas below read it by reference)
     const float* __restrict__ x = pcm;
     int n_valid = 0;
@@ -646,8 +649,14 @@ __global__ __launch_bounds__(64) void kaldi_stats_seq_kernel(
 __global__ __launch_bounds__(256) void kaldi_cmvn_kernel(
     float* __restrict__ out, const int32_t* __restrict__ lengths, const double* __restrict__ stats,
     int n_mels, int t_max, int max_frames, int flags, void* __restrict__ attn, int attn_bytes,
-    const int32_t* __restrict__ mask_tbl, int n_masks) {
+    const int32_t* __restrict__ mask_tbl, int n_masks, const KaldiTablesHeader* __restrict__ tab) {
     const int clip = blockIdx.y;
+    if (tab->magic != kKaldiMagic || tab->n_mels != n_mels) {
+        // tables built for another extractor: NaN everywhere instead of uninitialised memory (see sttfe.h)
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < t_max * n_mels; e += gridDim.x * blockDim.x)
+            out[(size_t)clip * t_max * n_mels + e] = __builtin_nanf("");
+        return;
+    }
     const int T = kaldi_num_frames(lengths[clip], max_frames, t_max);
     float* __restrict__ o = out + (size_t)clip * t_max * n_mels;
     const double* st = stats + (size_t)clip * 2 * n_mels;
@@ -747,13 +756,7 @@ extern "C" int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, 
     if (hip_failed(hipMemsetAsync(stats, 0, need, stream), "hipMemsetAsync(cmvn stats)")) return STTFE_E_LAUNCH;
     const auto* tab = reinterpret_cast<const KaldiTablesHeader*>(dev_tables);
     const int n_tiles = (t_max + kaldi::kTileFrames - 1) / kaldi::kTileFrames;
-    static const int resident = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-            cus = 256;
-        return 2 * cus;
-    }();
+    const int resident = 2 * current_device_cus();
     // persistent workgroups, two per CU; short runs keep ragged batches balanced: about eight items per workgroup,
     // taking half of batch x n_tiles as the batch's tiles (the lengths are on the device), within [2, 8] -- 2 tiles
     // (64 frames) for config 2's 256 clips (1: 0.123, 2: 0.111, 3: 0.119 ms), 3 at 1024 clips, 8 at 4096
@@ -790,7 +793,7 @@ extern "C" int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, 
         int cx = (t_max * n_mels + 255) / 256;
         if (cx > 64) cx = 64;
         hipLaunchKernelGGL(kaldi_cmvn_kernel, dim3(cx, batch), dim3(256), 0, stream, out, lengths, stats, n_mels,
-                           t_max, max_frames, flags, attn_mask, attn_mask_bytes, mask_tbl, n_masks);
+                           t_max, max_frames, flags, attn_mask, attn_mask_bytes, mask_tbl, n_masks, tab);
     }
     if (hip_failed(hipGetLastError(), "kaldi kernel launch")) return STTFE_E_LAUNCH;
     return STTFE_OK;

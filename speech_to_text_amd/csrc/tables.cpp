@@ -1,7 +1,7 @@
 // Host-side builders for the constant tables (mel banks, windows, twiddles, MFMA mel plans).
 // Pure C++ double-precision math; no GPU calls.  The filter-bank definitions follow the formulas
 // of the Hugging Face extractors the reference calls (HF:audio_utils.py:448-517,541-560,638-729);
-// tests/test_tables_cpu.py checks them against the NumPy oracle.
+// tests/test_boundary_cpu.py checks the banks and the resampler taps against the NumPy oracle.
 #include <algorithm>
 #include <cmath>
 #include <cstring>

@@ -23,7 +23,7 @@ bool g_enabled = false;
 // four events of its two kernels), so timing every launch would cost the timed region 7 % of its throughput.
 int g_stride = 1;
 unsigned g_seen[kTimedKernelCount] = {};
-const char* const kNames[kTimedKernelCount] = {"whisper_stft_mel", "whisper_clamp_mask", "kaldi_fbank",
+const char* const kNames[kTimedKernelCount] = {"whisper_stft_mel", "whisper_clamp_fill", "kaldi_fbank",
                                                "kaldi_cmvn", "resample_peak", "normalize_trim", "waveform_augment", "pitch_shift"};
 }  // namespace
 

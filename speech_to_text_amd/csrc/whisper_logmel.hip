@@ -34,6 +34,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 
@@ -158,6 +159,8 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     using namespace wh;
     __shared__ __attribute__((aligned(16))) float smem[kLdsFloats];
 
+    // a tables blob built for another extractor (wrong magic / n_mels): nothing is computed, kernel 2 poisons the output
+    if (tab->magic != kWhisperMagic || tab->n_mels != n_mels) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -606,10 +609,18 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     float* __restrict__ out, const int32_t* __restrict__ lengths, const unsigned* __restrict__ keys,
     int n_mels, int n_frames, const int32_t* __restrict__ mask_tbl, int n_masks,
-    const float* __restrict__ clip_scale, int mode, float pad_value) {
+    const float* __restrict__ clip_scale, int mode, float pad_value, const WhisperTablesHeader* __restrict__ tab) {
     using namespace wh;
     const int clip = blockIdx.y;
     const int row0 = blockIdx.x, row_step = gridDim.x;
+    if (tab->magic != kWhisperMagic || tab->n_mels != n_mels) {
+        // STTFE_E_TABLES cannot be returned without synchronising: the whole output becomes NaN instead (loud, and
+        // never uninitialised memory)
+        for (int mel = row0; mel < n_mels; mel += row_step)
+            for (int t = threadIdx.x; t < n_frames; t += blockDim.x)
+                out[((size_t)clip * n_mels + mel) * n_frames + t] = __builtin_nanf("");
+        return;
+    }
     // Everything the workgroup needs from memory is requested in ONE batch (length, max key, the per-tile min keys,
     // the clip's mask table -> LDS): with four dependent round trips per workgroup this kernel was latency-bound
     // (0.10 ms for 32 k workgroups that find nothing to clamp).
@@ -764,12 +775,27 @@ extern "C" int sttfe_whisper_workspace_bytes(int batch, size_t* bytes) {
 
 // Consecutive 48-frame tiles one workgroup of kernel 1 walks (tuning knob; 0 = automatic: long runs
 // when the batch alone fills the chip, shorter ones for small batches).
-static int g_whisper_tiles_per_block = 0;
+static std::atomic<int> g_whisper_tiles_per_block{0};       // read once per call: calls on other threads see old or new
 extern "C" int sttfe_set_whisper_tiles_per_block(int tiles) {
     if (tiles < 0 || tiles > wh::kMaxTiles) return STTFE_E_INVALID_ARG;
-    g_whisper_tiles_per_block = tiles;
+    g_whisper_tiles_per_block.store(tiles, std::memory_order_relaxed);
     return STTFE_OK;
 }
+
+namespace sttfe {
+// Compute units of the CURRENT device, looked up once per device (the library may serve several GPUs from one process).
+int current_device_cus() {
+    static std::atomic<int> cus_of[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int cus = cus_of[dev].load(std::memory_order_relaxed);
+    if (cus == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        cus_of[dev].store(cus, std::memory_order_relaxed);
+    }
+    return cus;
+}
+}  // namespace sttfe
 
 static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const int32_t* lengths,
                                int batch, int n_mels, int n_frames, const void* dev_tables,
@@ -796,18 +822,13 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
         const int v = e ? atoi(e) : 0;
         return v < 0 || v > wh::kMaxTiles ? 0 : v;
     }();
-    int tiles_per_block = g_whisper_tiles_per_block ? g_whisper_tiles_per_block : tpb_env;
+    const int tpb_knob = g_whisper_tiles_per_block.load(std::memory_order_relaxed);
+    int tiles_per_block = tpb_knob ? tpb_knob : tpb_env;
     // Kernel 1 runs as persistent workgroups (two per CU) that walk (tile run, clip) items; short runs keep the
     // workgroups balanced when clip lengths differ, and the tables are staged once per workgroup, not per run.
     // tiles_per_block == 0: the kernel picks the run length itself from the clip lengths it finds on the device
     if ((long)n_tiles * batch > 0x3fffffffL) return STTFE_E_UNSUPPORTED;
-    static const int resident = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-            cus = 256;
-        return 2 * cus;
-    }();
+    const int resident = 2 * current_device_cus();
     const long most_items = (long)batch * ((n_tiles + 2) / 3);      // fewer workgroups than that cannot all find work
     const int grid = most_items < resident ? (int)most_items : resident;
     const auto* tab = reinterpret_cast<const WhisperTablesHeader*>(dev_tables);
@@ -833,7 +854,7 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
         }();
         const int row_split = row_split_env ? row_split_env : (n_mels > 96 ? (n_mels + 3) / 4 : (n_mels + 4) / 5);
         hipLaunchKernelGGL(whisper_clamp_fill_kernel, dim3(row_split, batch), dim3(256), 0, stream, out, lengths, keys,
-                           n_mels, n_frames, mask_tbl, n_masks, clip_scale, mode, pad_value);
+                           n_mels, n_frames, mask_tbl, n_masks, clip_scale, mode, pad_value, tab);
     }
     if (hip_failed(hipGetLastError(), "whisper kernel launch")) return STTFE_E_LAUNCH;
     return STTFE_OK;

@@ -9,13 +9,16 @@ later epochs / runs read it back through ``FeatureCacheDataset``, whose samples 
 
 Layout of a cache directory (plain files, nothing executable)::
 
-    index.json        {"version", "model_type", "n_mels", "n_frames", "shards": [{"file", "clips": [...]}]}
-                      clip = {"id", "frames", "pad", "offset", "text", "labels"}
-    shard_00000.bin   float32, clip after clip: (n_mels, frames) row-major
+    index_rNN.json          one per writer rank NN: {"version", "model_type", "n_mels", "n_frames",
+                            "shards": [{"file", "clips": [...]}]}, clip = {"id", "frames", "pad", "offset", "text", "labels"}
+    shard_rNN_00000.bin     float32, clip after clip: (n_mels, frames) row-major
 
 Whisper features are constant behind the last computed 48-frame tile of a clip (zero padding to 30 s after
 log / clamp / scale), so only ``frames`` columns are stored and ``pad`` is that constant: a 5 s clip costs 0.17 MB
-instead of 0.96 MB.  Speech2Text features are stored whole ((freq, T), T = the clip's frame count).
+instead of 0.96 MB.  That holds for UN-AUGMENTED features only (the cache is for the evaluation splits): a SpecAugment
+frequency mask turns rows of the padding into 0.0 and a time mask can fall inside it, so ``add_batch`` checks that
+everything behind ``frames`` is one constant per clip and refuses the batch otherwise.
+Speech2Text features are stored whole ((freq, T), T = the clip's frame count).
 """
 from __future__ import annotations
 
@@ -75,6 +78,16 @@ class FeatureCacheWriter:
         t_max = max(keep) if keep else 0
         host = features[:, :, :t_max].to("cpu", non_blocking=False).contiguous().numpy()
         tail = features[:, 0, -1].to("cpu").numpy() if features.shape[2] > 0 else np.zeros(B, np.float32)
+        if self.model_type == "whisper" and features.shape[2] > 0:
+            # the truncated tail must be ONE constant per clip (true for un-augmented features; SpecAugment output is not)
+            kb = torch.as_tensor(keep, device=features.device)
+            col = torch.arange(features.shape[2], device=features.device)
+            behind = col[None, None, :] >= kb[:, None, None]
+            same = (features == features[:, :1, -1:]) | ~behind
+            if not bool(same.all()):
+                bad = (~same).flatten(1).any(dim=1).nonzero().flatten().tolist()
+                raise ValueError(f"clips {bad[:8]} are not constant behind their last computed tile (augmented "
+                                 "features?): the cache stores un-augmented features only")
         for b in range(B):
             if self._cur is None or len(self._cur["clips"]) >= self.shard_clips:
                 self._roll()

@@ -269,7 +269,14 @@ class GpuAudioPreprocessor:
         ``defer_normalize`` (with ``normalize``): the samples are left unnormalised and ``PackedAudio.scale`` carries
         1 / (max|x| + 1e-8) per clip (1 for silent clips, as src/data.py:79 skips them) for
         ``HipWhisperFeatureExtractor.extract(..., clip_scale=...)``, which folds it into the feature kernel -- one
-        pass over the waveform less.  Silence trimming is unaffected (its threshold is relative to the peak).
+        pass over the waveform less.  Silence trimming then compares raw samples with ``peak * threshold`` instead of
+        normalised ones with ``(peak / d) * threshold``: the bounds may differ by a sample where a sample sits exactly
+        at the threshold.
+
+        **In place:** mono float32 input at the target rate (no resample, no channel mix, no int16 conversion) is not
+        copied -- ``PackedAudio.pcm`` IS ``pcm_in`` and peak normalisation overwrites the caller's buffer.  A caller
+        that keeps decoded PCM resident across epochs passes ``pcm_in.clone()`` (or ``defer_normalize=True``, which
+        leaves the samples alone).
 
         ``sync_lengths`` (default: only when trimming) copies the trimmed lengths back to the host,
         which is what the duration gate and Speech2Text's dynamic padding need.

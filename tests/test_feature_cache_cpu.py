@@ -58,3 +58,23 @@ def test_speech2text_round_trip(tmp_path):
         assert torch.equal(ds[i]["input_features"], f[i, :, :t])
     batch = AudioCollator(DataConfig(), "speech2text", transpose_features=True)([ds[0], ds[1], ds[2]])
     assert batch["input_features"].shape == (3, 400, 80) and batch["attention_mask"].sum(1).tolist() == [98, 400, 1]
+
+
+def test_augmented_features_are_refused(tmp_path):
+    """The padding constant is stored once per clip: SpecAugment output (a zeroed mel row, a time mask inside the
+    padding) is not constant behind the last computed tile, and the writer says so instead of reading back wrong."""
+    import pytest
+    import torch
+    from speech_to_text_amd.feature_cache import FeatureCacheWriter
+    feats = torch.full((2, 80, 3000), -0.5)
+    feats[:, :, :96] = torch.randn(2, 80, 96)
+    w = FeatureCacheWriter(str(tmp_path), "whisper", 80)
+    w.add_batch([0, 1], feats, [8000, 8000])                        # fine: constant tail
+    masked = feats.clone()
+    masked[1, 0, :] = 0.0                                           # frequency mask over mel bin 0
+    with pytest.raises(ValueError, match="not constant behind"):
+        w.add_batch([2, 3], masked, [8000, 8000])
+    masked = feats.clone()
+    masked[0, :, 2000:2010] = 0.0                                   # time mask inside the padding
+    with pytest.raises(ValueError, match="not constant behind"):
+        w.add_batch([4, 5], masked, [8000, 8000])

@@ -84,3 +84,18 @@ def test_oracle_fade_and_gain_properties():
     y = W.apply_time_domain(np.ones(4000, np.float32), W.ClipDraw(fade_samples=1600))
     assert y[0] == 0.0 and y[-1] == 0.0 and np.all(y[1600:2400] == 1.0)
     assert np.all(np.diff(y[:1600]) > 0) and np.all(np.diff(y[-1600:]) < 0)
+
+
+def test_unsupported_speed_ratio_fails_at_construction():
+    """speed_num_steps=4 gives the factor 0.9667 -> int(15466.67) = 15466 : 16000 = 7733 : 8000 after reduction, which the
+    GPU resampler cannot run (reduced rates above 1024).  The sampler refuses the config when it is built, instead of
+    raising mid-epoch when that factor is drawn; the default (3 steps: 9:10, 1:1, 11:10) and 5 steps are fine."""
+    import pytest
+    from speech_to_text_amd.augment import WaveformAugmentSampler
+    WaveformAugmentSampler()                                   # defaults
+    WaveformAugmentSampler(speed_num_steps=5)                  # 0.9, 0.95, 1.0, 1.05, 1.1 -> 9:10, 19:20, 21:20, 11:10
+    with pytest.raises(ValueError, match="beyond the 1024:1024"):
+        WaveformAugmentSampler(speed_num_steps=4)
+    with pytest.raises(ValueError, match="beyond the 1024:1024"):
+        WaveformAugmentSampler(speed_num_steps=7)
+    WaveformAugmentSampler(speed_num_steps=4, speed_perturbation=False)     # not used -> not checked

@@ -146,3 +146,26 @@ def test_very_large_batch_of_short_clips():
     b = fe.extract(pcm, off[half:], ln[half:])
     assert torch.equal(full[:half], a) and torch.equal(full[half:], b)
     assert torch.isfinite(full).all()
+
+
+def test_mismatched_tables_poison_the_output(fe80, fe128):
+    """An 80-mel tables blob passed with n_mels=128 (or a Kaldi blob to the Whisper entry point) cannot be reported
+    without a sync: the kernels check the blob's header and turn the whole output into NaN -- never uninitialised rows."""
+    import ctypes
+    from speech_to_text_amd import _lib
+    from speech_to_text_amd.processors import HipSpeech2TextFeatureExtractor, pack_clips
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    clips = synth_batch(3, [16000, 480000])
+    pcm, off, ln = pack_clips(list(clips), dev, 480000)
+    n = ctypes.c_size_t()
+    _lib.check(L.sttfe_whisper_workspace_bytes(2, ctypes.byref(n)))
+    ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
+    kaldi_tab = HipSpeech2TextFeatureExtractor(device=dev)._tables_on(dev)
+    for tables, n_mels in ((fe80._tables_on(dev), 128), (fe128._tables_on(dev), 80), (kaldi_tab, 80)):
+        out = torch.zeros((2, n_mels, 3000), dtype=torch.float32, device=dev)
+        rc = L.sttfe_whisper_logmel(_lib.ptr(pcm), _lib.ptr(off), _lib.ptr(ln), 2, n_mels, 3000, _lib.ptr(tables),
+                                    _lib.ptr(out), None, 0, _lib.ptr(ws), ws.numel(),
+                                    ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        assert rc == 0
+        assert bool(torch.isnan(out).all())

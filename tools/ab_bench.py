@@ -45,7 +45,7 @@ for tpb in knobs:
     t, n = ctypes.c_double(), ctypes.c_int()
     L.sttfe_timing_query(b"whisper_stft_mel", ctypes.byref(t), ctypes.byref(n))
     t2, n2 = ctypes.c_double(), ctypes.c_int()
-    L.sttfe_timing_query(b"whisper_clamp_mask", ctypes.byref(t2), ctypes.byref(n2))
+    L.sttfe_timing_query(b"whisper_clamp_fill", ctypes.byref(t2), ctypes.byref(n2))
     L.sttfe_timing_enable(0)
     ms = t.value / 8
     print(f"tpb={tpb:3d} stft_mel {ms:.3f} ms/step ({n.value//8} launches)  clamp {t2.value/8:.3f} ms  "
