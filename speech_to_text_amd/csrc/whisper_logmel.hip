@@ -147,6 +147,49 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #define STAMP(i)
 #endif
 
+// ---- static mel plan of the 80-bin extractor (the headline configuration) -------------------------------------
+// tables.cpp derives the banded plan from the mel bank at run time; for n_mels == 80 the result is always the one
+// below (the kernel compares the blob's plan with it once and falls back to the generic unit loop otherwise).
+// With the plan known at compile time a unit's MFMA sequence is fully unrolled: operand reads are ds_read_b128 with
+// immediate offsets off two per-lane base registers, the first steps take an inline zero accumulator, the stores use
+// one scalar base per unit + four per-lane offsets computed once per kernel, and no descriptor is read per tile.
+namespace wh {
+constexpr int kPlan80Kstart[5] = {0, 12, 28, 56, 104};
+constexpr int kPlan80Nsteps[5] = {4, 8, 8, 16, 24};
+constexpr int kPlan80Aoff[5] = {0, 256, 768, 1280, 2304};
+}  // namespace wh
+
+// One (mel tile MT, frame tile FT) unit of a whole, unmasked 48-frame tile of an 80-bin extractor.
+//   a_lane : this lane's A-operand base (mel weights, LDS), b_lane : its B-operand row base of frame tile FT (panel)
+//   out_u  : scalar pointer out_clip + t0 + MT * 16 * n_frames + FT * 16;  o_r : per-lane store offsets, r = 0..3
+template <int MT>
+__device__ __forceinline__ void mel_unit80(const float* __restrict__ a_lane, const float* __restrict__ b_lane,
+                                           float* __restrict__ out_u, const unsigned (&o_r)[4], float mel_floor,
+                                           float y_bias, float& run_max, float& tile_min) {
+    using namespace wh;
+    constexpr int KS = kPlan80Kstart[MT], NG = kPlan80Nsteps[MT] / 4, AO = kPlan80Aoff[MT];
+    const f32x4* __restrict__ a = reinterpret_cast<const f32x4*>(a_lane + AO);
+    const f32x4* __restrict__ b = reinterpret_cast<const f32x4*>(b_lane + KS);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const f32x4 av = a[g * 64], bv = b[4 * g];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc2, 0, 0, 0);
+    }
+    acc += acc2;
+    float mv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        mv[r] = fmaxf(acc[r], mel_floor);
+        out_u[o_r[r]] = fmaf(__log2f(mv[r]), 0.25f * 0.30102999566398120f, y_bias);
+    }
+    run_max = fmaxf(fmaxf(run_max, fmaxf(mv[0], mv[1])), fmaxf(mv[2], mv[3]));
+    tile_min = fminf(fminf(tile_min, fminf(mv[0], mv[1])), fminf(mv[2], mv[3]));
+}
+
 #ifndef STTFE_WH_WAVES_PER_SIMD
 #define STTFE_WH_WAVES_PER_SIMD 2
 #endif
@@ -383,6 +426,17 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         return fw * kSlabFloats + (fl - fw * kFramesPerWave) * kPStride + 4 * (lane >> 4);
     };
     const int brow0 = b_row(0), brow1 = b_row(1), brow2 = b_row(2);
+    // static 80-bin plan (mel_unit80): usable when the blob's plan is the one compiled in
+    bool plan80 = n_mels == 80 && tab->plan.n_mtiles == 5;
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt)
+        plan80 = plan80 && tab->plan.kstart[mt] == kPlan80Kstart[mt] && tab->plan.nsteps[mt] == kPlan80Nsteps[mt] &&
+                 tab->plan.aoff[mt] == kPlan80Aoff[mt];
+    plan80 = __builtin_amdgcn_readfirstlane(plan80 ? 1 : 0) != 0;
+    const float* a_lane = smem + kAfragOff + 4 * lane;
+    unsigned o_r[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o_r[r] = (unsigned)(((lane >> 4) * 4 + r) * n_frames + (lane & 15));
 #ifdef STTFE_STAMPS
     unsigned long long stamp_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
@@ -489,6 +543,37 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         // operands -- across unit boundaries too -- are read while the current four steps multiply.
         // (Running a unit's epilogue under the first MFMAs of the next unit was measured slower: 1.15 vs 1.08 ms.)
         float tile_min = 3.0e38f;
+        if (plan80 && nm == 0 && t0 + kTileFrames <= min(n_frames, key_frames)) {
+            // whole, unmasked tile of the 80-bin extractor: the wave's units from the static plan (same assignment as
+            // tables.cpp's: 48 / 44 / 44 / 44 k-steps per wave)
+            float* __restrict__ ob = out_clip + t0;
+            const float* b0 = smem + brow0;
+            const float* b1 = smem + brow1;
+            const float* b2 = smem + brow2;
+            const size_t nf16 = (size_t)16 * n_frames;
+#define STTFE_U80(MT, FT, B) mel_unit80<MT>(a_lane, B, ob + MT * nf16 + FT * 16, o_r, mel_floor, y_bias, run_max, tile_min)
+            if (wave == 0) {
+                STTFE_U80(4, 0, b0);
+                STTFE_U80(3, 2, b2);
+                STTFE_U80(2, 2, b2);
+            } else if (wave == 1) {
+                STTFE_U80(4, 1, b1);
+                STTFE_U80(1, 0, b0);
+                STTFE_U80(1, 1, b1);
+                STTFE_U80(0, 0, b0);
+            } else if (wave == 2) {
+                STTFE_U80(4, 2, b2);
+                STTFE_U80(2, 0, b0);
+                STTFE_U80(2, 1, b1);
+                STTFE_U80(0, 1, b1);
+            } else {
+                STTFE_U80(3, 0, b0);
+                STTFE_U80(3, 1, b1);
+                STTFE_U80(1, 2, b2);
+                STTFE_U80(0, 2, b2);
+            }
+#undef STTFE_U80
+        } else {
         int4v d = desc[0];                                          // {kstart, nsteps, aoff, mt | ft << 8}
         int ks = __builtin_amdgcn_readfirstlane(d.x), ns = __builtin_amdgcn_readfirstlane(d.y);
         int ao = __builtin_amdgcn_readfirstlane(d.z), code = __builtin_amdgcn_readfirstlane(d.w);
@@ -567,6 +652,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
             }
             STAMP(1);
         }
+        }   // generic unit loop
         // per-tile minimum (kernel 2 re-reads only the tiles that hold something below max - 8)
         tile_min = wave_min(tile_min);
         if (lane == 0 && tile_min < 1.0e38f)
