@@ -147,27 +147,44 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #define STAMP(i)
 #endif
 
-// ---- static mel plan of the 80-bin extractor (the headline configuration) -------------------------------------
-// tables.cpp derives the banded plan from the mel bank at run time; for n_mels == 80 the result is always the one
-// below (the kernel compares the blob's plan with it once and falls back to the generic unit loop otherwise).
+// ---- static mel plans of the 80- and 128-bin extractors ---------------------------------------------------------
+// tables.cpp derives the banded plan from the mel bank at run time; for n_mels == 80 and 128 (the two Whisper
+// configurations) the result is always the one below (the kernel compares the blob's plan with it once and falls back
+// to the generic unit loop otherwise).
 // With the plan known at compile time a unit's MFMA sequence is fully unrolled: operand reads are ds_read_b128 with
 // immediate offsets off two per-lane base registers, the first steps take an inline zero accumulator, the stores use
 // one scalar base per unit + four per-lane offsets computed once per kernel, and no descriptor is read per tile.
 namespace wh {
-constexpr int kPlan80Kstart[5] = {0, 12, 28, 56, 104};
-constexpr int kPlan80Nsteps[5] = {4, 8, 8, 16, 24};
-constexpr int kPlan80Aoff[5] = {0, 256, 768, 1280, 2304};
+template <int NM> struct StaticPlan;
+template <> struct StaticPlan<80> {
+    static constexpr int n = 5;
+    static constexpr int kstart[5] = {0, 12, 28, 56, 104}, nsteps[5] = {4, 8, 8, 16, 24}, aoff[5] = {0, 256, 768, 1280, 2304};
+};
+template <> struct StaticPlan<128> {
+    static constexpr int n = 8;
+    static constexpr int kstart[8] = {0, 8, 16, 28, 40, 60, 88, 124}, nsteps[8] = {4, 4, 4, 4, 8, 12, 12, 20},
+                         aoff[8] = {0, 256, 512, 768, 1024, 1536, 2304, 3072};
+};
+template <int NM>
+__device__ __forceinline__ bool plan_matches(const MelPlan& p) {
+    bool ok = p.n_mtiles == StaticPlan<NM>::n;
+#pragma unroll
+    for (int mt = 0; mt < StaticPlan<NM>::n; ++mt)
+        ok = ok && p.kstart[mt] == StaticPlan<NM>::kstart[mt] && p.nsteps[mt] == StaticPlan<NM>::nsteps[mt] &&
+             p.aoff[mt] == StaticPlan<NM>::aoff[mt];
+    return ok;
+}
 }  // namespace wh
 
-// One (mel tile MT, frame tile FT) unit of a whole, unmasked 48-frame tile of an 80-bin extractor.
+// One (mel tile MT, frame tile FT) unit of a whole, unmasked 48-frame tile of an NM-bin extractor.
 //   a_lane : this lane's A-operand base (mel weights, LDS), b_lane : its B-operand row base of frame tile FT (panel)
 //   out_u  : scalar pointer out_clip + t0 + MT * 16 * n_frames + FT * 16;  o_r : per-lane store offsets, r = 0..3
-template <int MT>
-__device__ __forceinline__ void mel_unit80(const float* __restrict__ a_lane, const float* __restrict__ b_lane,
+template <int NM, int MT>
+__device__ __forceinline__ void mel_unit_static(const float* __restrict__ a_lane, const float* __restrict__ b_lane,
                                            float* __restrict__ out_u, const unsigned (&o_r)[4], float mel_floor,
                                            float y_bias, float& run_max, float& tile_min) {
-    using namespace wh;
-    constexpr int KS = kPlan80Kstart[MT], NG = kPlan80Nsteps[MT] / 4, AO = kPlan80Aoff[MT];
+    using P = wh::StaticPlan<NM>;
+    constexpr int KS = P::kstart[MT], NG = P::nsteps[MT] / 4, AO = P::aoff[MT];
     const f32x4* __restrict__ a = reinterpret_cast<const f32x4*>(a_lane + AO);
     const f32x4* __restrict__ b = reinterpret_cast<const f32x4*>(b_lane + KS);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
@@ -426,13 +443,9 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         return fw * kSlabFloats + (fl - fw * kFramesPerWave) * kPStride + 4 * (lane >> 4);
     };
     const int brow0 = b_row(0), brow1 = b_row(1), brow2 = b_row(2);
-    // static 80-bin plan (mel_unit80): usable when the blob's plan is the one compiled in
-    bool plan80 = n_mels == 80 && tab->plan.n_mtiles == 5;
-#pragma unroll
-    for (int mt = 0; mt < 5; ++mt)
-        plan80 = plan80 && tab->plan.kstart[mt] == kPlan80Kstart[mt] && tab->plan.nsteps[mt] == kPlan80Nsteps[mt] &&
-                 tab->plan.aoff[mt] == kPlan80Aoff[mt];
-    plan80 = __builtin_amdgcn_readfirstlane(plan80 ? 1 : 0) != 0;
+    // static plan (mel_unit_static): usable when the blob's plan is one of those compiled in
+    const int static_plan = __builtin_amdgcn_readfirstlane(
+        n_mels == 80 && plan_matches<80>(tab->plan) ? 80 : (n_mels == 128 && plan_matches<128>(tab->plan) ? 128 : 0));
     const float* a_lane = smem + kAfragOff + 4 * lane;
     unsigned o_r[4];
 #pragma unroll
@@ -543,36 +556,42 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         // operands -- across unit boundaries too -- are read while the current four steps multiply.
         // (Running a unit's epilogue under the first MFMAs of the next unit was measured slower: 1.15 vs 1.08 ms.)
         float tile_min = 3.0e38f;
-        if (plan80 && nm == 0 && t0 + kTileFrames <= min(n_frames, key_frames)) {
-            // whole, unmasked tile of the 80-bin extractor: the wave's units from the static plan (same assignment as
-            // tables.cpp's: 48 / 44 / 44 / 44 k-steps per wave)
+        if (static_plan != 0 && nm == 0 && t0 + kTileFrames <= min(n_frames, key_frames)) {
+            // whole, unmasked tile of an 80- or 128-bin extractor: the wave's units from the static plan (the same
+            // assignment as tables.cpp's: 48 / 44 / 44 / 44 k-steps per wave for 80 bins, 52 / 52 / 52 / 48 for 128)
             float* __restrict__ ob = out_clip + t0;
             const float* b0 = smem + brow0;
             const float* b1 = smem + brow1;
             const float* b2 = smem + brow2;
             const size_t nf16 = (size_t)16 * n_frames;
-#define STTFE_U80(MT, FT, B) mel_unit80<MT>(a_lane, B, ob + MT * nf16 + FT * 16, o_r, mel_floor, y_bias, run_max, tile_min)
-            if (wave == 0) {
-                STTFE_U80(4, 0, b0);
-                STTFE_U80(3, 2, b2);
-                STTFE_U80(2, 2, b2);
-            } else if (wave == 1) {
-                STTFE_U80(4, 1, b1);
-                STTFE_U80(1, 0, b0);
-                STTFE_U80(1, 1, b1);
-                STTFE_U80(0, 0, b0);
-            } else if (wave == 2) {
-                STTFE_U80(4, 2, b2);
-                STTFE_U80(2, 0, b0);
-                STTFE_U80(2, 1, b1);
-                STTFE_U80(0, 1, b1);
+#define STTFE_U(NM, MT, FT) \
+    mel_unit_static<NM, MT>(a_lane, b##FT, ob + MT * nf16 + FT * 16, o_r, mel_floor, y_bias, run_max, tile_min)
+            if (static_plan == 80) {
+                if (wave == 0) {
+                    STTFE_U(80, 4, 0); STTFE_U(80, 3, 2); STTFE_U(80, 2, 2);
+                } else if (wave == 1) {
+                    STTFE_U(80, 4, 1); STTFE_U(80, 1, 0); STTFE_U(80, 1, 1); STTFE_U(80, 0, 0);
+                } else if (wave == 2) {
+                    STTFE_U(80, 4, 2); STTFE_U(80, 2, 0); STTFE_U(80, 2, 1); STTFE_U(80, 0, 1);
+                } else {
+                    STTFE_U(80, 3, 0); STTFE_U(80, 3, 1); STTFE_U(80, 1, 2); STTFE_U(80, 0, 2);
+                }
             } else {
-                STTFE_U80(3, 0, b0);
-                STTFE_U80(3, 1, b1);
-                STTFE_U80(1, 2, b2);
-                STTFE_U80(0, 2, b2);
+                if (wave == 0) {
+                    STTFE_U(128, 7, 0); STTFE_U(128, 5, 1); STTFE_U(128, 4, 0);
+                    STTFE_U(128, 1, 0); STTFE_U(128, 1, 1); STTFE_U(128, 1, 2);
+                } else if (wave == 1) {
+                    STTFE_U(128, 7, 1); STTFE_U(128, 6, 1); STTFE_U(128, 4, 1);
+                    STTFE_U(128, 2, 0); STTFE_U(128, 2, 1); STTFE_U(128, 2, 2);
+                } else if (wave == 2) {
+                    STTFE_U(128, 7, 2); STTFE_U(128, 5, 2); STTFE_U(128, 4, 2);
+                    STTFE_U(128, 3, 0); STTFE_U(128, 3, 1); STTFE_U(128, 3, 2);
+                } else {
+                    STTFE_U(128, 5, 0); STTFE_U(128, 6, 0); STTFE_U(128, 6, 2);
+                    STTFE_U(128, 0, 0); STTFE_U(128, 0, 1); STTFE_U(128, 0, 2);
+                }
             }
-#undef STTFE_U80
+#undef STTFE_U
         } else {
         int4v d = desc[0];                                          // {kstart, nsteps, aoff, mt | ft << 8}
         int ks = __builtin_amdgcn_readfirstlane(d.x), ns = __builtin_amdgcn_readfirstlane(d.y);
