@@ -25,6 +25,8 @@
 #include <stdlib.h>
 
 #include "../../include/sttfe.h"
+#include <type_traits>
+
 #include "fft_core.h"
 #include "tables.h"
 #include "timing.h"
@@ -51,55 +53,19 @@ constexpr int kTwOff = kWinOff + 400;
 constexpr int kAfragOff = kTwOff + 1024;
 constexpr int kMaxAfragFloats = 0;         // the mel weights are read from global memory (L1 / L2 resident)
 constexpr int kDescOff = kAfragOff + kMaxAfragFloats;  // per wave: 8 x {kstart, nsteps, aoff, mt | ft << 8}, then the unit counts
-constexpr int kF64TabOff = kDescOff + kWaves * kMaxUnitsPerWave * 4 + kWaves + 3 & ~3;   // float64 mode: mel bands + weights
-constexpr int kMaxBandWeights = 520;       // a triangular bank over 257 bins has at most 2 non-zero weights per bin
-constexpr int kLdsFloats = kF64TabOff + 4 * 128 + 2 * kMaxBandWeights;            // 80 KB: two workgroups per CU
+constexpr int kLdsFloats = (kDescOff + kWaves * kMaxUnitsPerWave * 4 + kWaves + 3) & ~3;    // 74 KB: two workgroups per CU
 constexpr int kUnitsCap = 4;               // units one wave owns: ceil(8 mel tiles x 2 frame tiles / 4 waves) at most
 constexpr float kMelFloor = 1.1920928955078125e-07f;
 }  // namespace kaldi
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int int4k __attribute__((ext_vector_type(4)));
+typedef double double2k __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void wave_lds_sync2() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// ---- float64 pieces of the STTFE_KALDI_F64 mode (HF's NumPy path frames, windows and transforms in float64,
-// HF:audio_utils.py:957-988, and only then rounds each spectrum to complex64) ----
-struct cd {
-    double x, y;
-};
-__device__ __forceinline__ cd operator+(cd a, cd b) { return cd{a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cd operator-(cd a, cd b) { return cd{a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ cd cmuld(cd a, cd b) { return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-__device__ __forceinline__ void dft4d(cd& a0, cd& a1, cd& a2, cd& a3) {
-    const cd s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
-    a0 = s02 + s13;
-    a2 = s02 - s13;
-    a1 = cd{d02.x + d13.y, d02.y - d13.x};      // d02 - i d13
-    a3 = cd{d02.x - d13.y, d02.y + d13.x};      // d02 + i d13
-}
-// 8-point forward DFT in place, natural order in / out (2 x 4 Cooley-Tukey, as dft8 of fft_core.h)
-__device__ __forceinline__ void dft8d(cd (&v)[8]) {
-    constexpr double kH = 0.70710678118654752440;
-    cd e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
-    cd o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
-    dft4d(e0, e1, e2, e3);
-    dft4d(o0, o1, o2, o3);
-    const cd w1{(o1.x + o1.y) * kH, (o1.y - o1.x) * kH};       // * (1 - i) / sqrt 2
-    const cd w2{o2.y, -o2.x};                                  // * -i
-    const cd w3{(o3.y - o3.x) * kH, -(o3.x + o3.y) * kH};      // * (-1 - i) / sqrt 2
-    v[0] = e0 + o0;
-    v[4] = e0 - o0;
-    v[1] = e1 + w1;
-    v[5] = e1 - w1;
-    v[2] = e2 + w2;
-    v[6] = e2 - w2;
-    v[3] = e3 + w3;
-    v[7] = e3 - w3;
 }
 
 __device__ __forceinline__ int kaldi_num_frames(int n, int max_frames, int t_max) {
@@ -117,7 +83,6 @@ __device__ __forceinline__ int kaldi_num_frames(int n, int max_frames, int t_max
 // item.  The loop ends after at most n_items tickets; all threads of a workgroup take the same path.
 // (Requesting the next item's ticket, length and first PCM tile an item ahead, as the Whisper kernel does, needs
 // one of the two PCM passes to be fetched late for register room and was measured slower: 0.127 ms.)
-template <bool kF64>
 __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     const float* __restrict__ pcm, const int64_t* __restrict__ offsets,
     const int32_t* __restrict__ lengths, int n_mels, int t_max, int max_frames,
@@ -207,44 +172,6 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     };
     const int prow0 = p_row(0), prow1 = p_row(1);
 
-    // float64 mode: one frame pair at a time per wave as ONE complex 512-point DFT, 8 x 8 x 8: lane l holds
-    // z[l + 64 m]; three register-resident 8-point DFTs with two transposes through an 8 KB per-wave exchange area
-    // (the part of the wave's slab that its panel rows do not cover; 16-byte complex cells, XOR-swizzled columns so
-    // that both the row-wise writes and the column-wise reads are bank-conflict free).  The lane's window column and
-    // twiddles W512^(l q), W64^((l & 7) s) stay in registers for the whole kernel.
-    double win64[7];
-    cd tw1[8], tw2[8];
-    // float64 mode uses the wave's slab as: 8 KB exchange area, then the pair's two float64 power rows (258 doubles each)
-    cd* exch = reinterpret_cast<cd*>(my_rows);
-    double* pp = reinterpret_cast<double*>(my_rows) + 1024;
-    static_assert(8192 + 4 * 258 * 8 <= kSlabFloats * 4, "float64 exchange area + power rows must fit in the wave's slab");
-    const int4k* band64 = reinterpret_cast<const int4k*>(smem + kF64TabOff);   // per mel bin {first FFT bin, bins, weight offset, 0}
-    const double* wts64 = reinterpret_cast<const double*>(smem + kF64TabOff + 4 * 128);
-    if constexpr (kF64) {
-        const double* __restrict__ t64 = reinterpret_cast<const double*>(
-            reinterpret_cast<const char*>(tab + 1) + (((size_t)tab->afrag_floats * 4 + 7) & ~(size_t)7));
-#pragma unroll
-        for (int m = 0; m < 7; ++m) win64[m] = (lane + 64 * m < kFrame) ? t64[lane + 64 * m] : 0.0;
-        {   // the float64 mel bank (bands + weights) goes to LDS once per workgroup
-            const int nm = min(tab->n_mels, 128);
-            const int4k* __restrict__ bg = reinterpret_cast<const int4k*>(t64 + kFrame + 1024);
-            const double* __restrict__ wg = t64 + kFrame + 1024 + 2 * nm;
-            int4k* bl = reinterpret_cast<int4k*>(smem + kF64TabOff);
-            double* wl = reinterpret_cast<double*>(smem + kF64TabOff + 4 * 128);
-            for (int i = tid; i < nm; i += kThreads) bl[i] = bg[i];
-            const int nw = min(tab->reserved, kMaxBandWeights);
-            for (int i = tid; i < nw; i += kThreads) wl[i] = wg[i];
-            __syncthreads();
-        }
-        const double* __restrict__ w512 = t64 + kFrame;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int i1 = (lane * q) & 511, i2 = (8 * (lane & 7) * q) & 511;
-            tw1[q] = cd{w512[2 * i1], w512[2 * i1 + 1]};
-            tw2[q] = cd{w512[2 * i2], w512[2 * i2 + 1]};
-        }
-    }
-
     unsigned iter = 0;
     while (item < n_items) {
     unsigned my_ticket = 0;
@@ -263,10 +190,8 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     if (tile_begin < tile_end) {
     float* __restrict__ out_clip = out + (size_t)clip * t_max * n_mels;
     double* __restrict__ st = stats + (size_t)clip * 2 * n_mels;
-    if constexpr (!kF64) {
-        load_pass(tile_begin * kTileFrames, 0, raw0, prv0);
-        load_pass(tile_begin * kTileFrames, 1, raw1, prv1);
-    }
+    load_pass(tile_begin * kTileFrames, 0, raw0, prv0);
+    load_pass(tile_begin * kTileFrames, 1, raw1, prv1);
 
     // CMVN sums of this wave's units over the item (a wave owns the same (mel tile, frame tile) units in every tile)
     double s1[kUnitsCap], s2[kUnitsCap];
@@ -275,141 +200,6 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
 
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const int t0 = tile * kTileFrames;
-        if constexpr (kF64) {
-            // samples x[n], x[n - 1] of the pair's two frames for n = lane + 64 m (frame b starts one hop later)
-            auto load_pair = [&](int pair, float (&xa)[7], float (&xap)[7], float (&xb)[7], float (&xbp)[7]) {
-                const int base = kHop * (t0 + wave * kFramesPerWave + 2 * pair) + lane;
-#pragma unroll
-                for (int m = 0; m < 7; ++m) {
-                    const int ia = base + 64 * m, ib = ia + kHop;
-                    const bool in_frame = lane + 64 * m < kFrame;
-                    xa[m] = (in_frame && ia < n_valid) ? x[ia] : 0.0f;
-                    xap[m] = (in_frame && ia < n_valid && ia > 0) ? x[ia - 1] : 0.0f;
-                    xb[m] = (in_frame && ib < n_valid) ? x[ib] : 0.0f;
-                    xbp[m] = (in_frame && ib < n_valid) ? x[ib - 1] : 0.0f;
-                }
-            };
-            auto fft_pair = [&](int pair, const float (&xa)[7], const float (&xap)[7], const float (&xb)[7],
-                                const float (&xbp)[7]) {
-                // per-frame mean over the 400 samples (HF:audio_utils.py:979-980), float64
-                double sa = 0.0, sb = 0.0;
-#pragma unroll
-                for (int m = 0; m < 7; ++m) {
-                    sa += (double)xa[m];
-                    sb += (double)xb[m];
-                }
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    sa += __shfl_xor(sa, off, 64);
-                    sb += __shfl_xor(sb, off, 64);
-                }
-                const double mu_a = sa / 400.0, mu_b = sb / 400.0;
-                cd v[8];
-#pragma unroll
-                for (int m = 0; m < 7; ++m) {
-                    // buffer - mean; buffer[1:] -= 0.97 buffer[:-1]; buffer[0] *= 1 - 0.97; * window (:979-986)
-                    const double da = (double)xa[m] - mu_a, db = (double)xb[m] - mu_b;
-                    double ea = da - 0.97 * ((double)xap[m] - mu_a);
-                    double eb = db - 0.97 * ((double)xbp[m] - mu_b);
-                    if (m == 0 && lane == 0) {
-                        ea = da * (1.0 - 0.97);
-                        eb = db * (1.0 - 0.97);
-                    }
-                    v[m] = cd{ea * win64[m], eb * win64[m]};          // win64 is 0 past the frame
-                }
-                v[7] = cd{0.0, 0.0};
-                dft8d(v);                                             // over m: Y_l[q]
-                wave_lds_sync2();                                     // after the previous pair's reads
-                {
-                    cd* row = exch + lane * 8;
-                    const int sw = lane & 7;
-                    row[sw] = v[0];
-#pragma unroll
-                    for (int q = 1; q < 8; ++q) row[q ^ sw] = cmuld(v[q], tw1[q]);
-                }
-                wave_lds_sync2();
-                {
-                    const int l0 = lane & 7, q2 = lane >> 3;          // lane = l0 + 8 q: rows l0 + 8 l1, column q
-                    const cd* col = exch + l0 * 8 + (q2 ^ l0);
-#pragma unroll
-                    for (int l1 = 0; l1 < 8; ++l1) v[l1] = col[64 * l1];
-                    wave_lds_sync2();
-                    dft8d(v);                                         // over l1: U[l0][s][q]
-                    cd* dst = exch + q2 * 64;
-                    const int sw = l0 ^ q2;
-                    dst[sw] = v[0];
-#pragma unroll
-                    for (int s2 = 1; s2 < 8; ++s2) dst[s2 * 8 + (sw ^ s2)] = cmuld(v[s2], tw2[s2]);
-                }
-                wave_lds_sync2();
-                {
-                    const int q3 = lane & 7, s3 = lane >> 3;          // lane = q + 8 s = bin index mod 64
-                    const cd* src = exch + q3 * 64 + s3 * 8;
-                    const int sw = s3 ^ q3;
-#pragma unroll
-                    for (int l0 = 0; l0 < 8; ++l0) v[l0] = src[l0 ^ sw];
-                    dft8d(v);                                         // over l0: v[t] = Z[lane + 64 t]
-                }
-                // spectra of the two real frames: A[k] = (Z[k] + conj Z[512 - k]) / 2, B[k] = (Z[k] - conj Z[512 - k]) / 2i,
-                // each rounded to complex64 as HF stores them (:966, :988), then |.|^2 (the 1/4 is in the mel bank)
-                const int partner = (64 - lane) & 63;
-                double* prow = pp + (pair & 1) * 2 * 258 + lane;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    double qr = __shfl(v[7 - t].x, partner, 64);
-                    double qi = __shfl(v[7 - t].y, partner, 64);
-                    if (lane == 0) {
-                        qr = v[(8 - t) & 7].x;
-                        qi = v[(8 - t) & 7].y;
-                    }
-                    const double sr = (double)(float)(v[t].x + qr), dr = (double)(float)(v[t].x - qr);
-                    const double si = (double)(float)(v[t].y + qi), di = (double)(float)(v[t].y - qi);
-                    prow[64 * t] = sr * sr + di * di;                 // np.abs(complex64, dtype=float64) ** 2 (:993)
-                    prow[258 + 64 * t] = si * si + dr * dr;
-                }
-                if (lane == 0) {                                      // bin 256
-                    const double ar = (double)(float)(2.0 * v[4].x), br = (double)(float)(2.0 * v[4].y);
-                    prow[256] = ar * ar;
-                    prow[258 + 256] = br * br;
-                }
-            };
-            // mel projection and log in float64, rounded to float32 once (:998-1015), for the four frames of two pairs:
-            // lane -> (frame, mel bin); 4 n_mels outputs = five full rounds of the wave for 80 bins
-            auto mel_rows = [&](int first_pair) {
-                wave_lds_sync2();
-                for (int o = lane; o < 4 * n_mels; o += 64) {
-                    const int fr = o / n_mels, mel = o - fr * n_mels;
-                    const int4k b = band64[mel];
-                    const double* w = wts64 + b.z;
-                    const double* pr = pp + fr * 258 + b.x;
-                    double acc = 0.0;
-                    int jj = 0;
-                    for (; jj + 4 <= b.y; jj += 4) {
-                        const double w0 = w[jj], w1 = w[jj + 1], w2 = w[jj + 2], w3 = w[jj + 3];
-                        const double p0 = pr[jj], p1 = pr[jj + 1], p2 = pr[jj + 2], p3 = pr[jj + 3];
-                        acc += w0 * p0;
-                        acc += w1 * p1;
-                        acc += w2 * p2;
-                        acc += w3 * p3;
-                    }
-                    for (; jj < b.y; ++jj) acc += w[jj] * pr[jj];
-                    const int t = t0 + wave * kFramesPerWave + 2 * first_pair + fr;
-                    if (t < T) out_clip[(unsigned)(t * n_mels + mel)] = (float)log(fmax(acc, 1.192092955078125e-07));
-                }
-            };
-            float xa0[7], xp0[7], xb0[7], xq0[7], xa1[7], xp1[7], xb1[7], xq1[7];
-            load_pair(0, xa0, xp0, xb0, xq0);
-            load_pair(1, xa1, xp1, xb1, xq1);
-            fft_pair(0, xa0, xp0, xb0, xq0);
-            load_pair(2, xa0, xp0, xb0, xq0);
-            fft_pair(1, xa1, xp1, xb1, xq1);
-            load_pair(3, xa1, xp1, xb1, xq1);
-            mel_rows(0);
-            fft_pair(2, xa0, xp0, xb0, xq0);
-            fft_pair(3, xa1, xp1, xb1, xq1);
-            mel_rows(2);
-            continue;       // wave-local from PCM to log-mel: no workgroup barrier, no matrix-core phase in this mode
-        } else {
         auto stage1 = [&](int r, const float (&raw)[18], const float (&prv)[18]) {
             const int pair = 2 * r + h;
             // window column and twiddles: all LDS reads are issued before the first slab write (the compiler
@@ -495,7 +285,6 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
             load_pass(t0 + kTileFrames, 0, raw0, prv0);
             load_pass(t0 + kTileFrames, 1, raw1, prv1);
         }
-        }   // float32 transform
         __syncthreads();
 
         // ---------------- banded mel projection (frames x mels) + ln + CMVN statistics -----------
@@ -563,7 +352,7 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     // (float64 mode: kaldi_stats_seq_kernel reproduces NumPy's sequential float32 reductions instead)
 #pragma unroll
     for (int u = 0; u < kUnitsCap; ++u) {
-        if (!kF64 && u < nu) {
+        if (u < nu) {
             double a = s1[u], b2 = s2[u];
             a += __shfl_xor(a, 16, 64);
             b2 += __shfl_xor(b2, 16, 64);
@@ -585,6 +374,358 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     item = (int)min(s_next[iter & 1u], (unsigned)n_items);
     ++iter;
     }   // items
+}
+
+// =====================================================================================================================
+// STTFE_KALDI_F64: HF's NumPy path frames, windows and transforms in float64 (HF:audio_utils.py:957-988) and only then
+// rounds each spectrum to complex64; the mel projection and the logarithm are float64 again and the result is rounded
+// to float32 once (:993-1015).  This kernel does the same arithmetic, a wave at a time, without matrix cores.
+//
+// A wave owns 8 frames of a 32-frame tile and handles them as 4 frame pairs: the two real frames of a pair are the
+// real and imaginary part of ONE complex 512-point DFT, done as 8 x 8 x 8: lane l holds z[l + 64 m]; three
+// register-resident 8-point DFTs with two transposes through an 8 KB per-wave exchange area (16-byte complex cells,
+// XOR-swizzled columns so that both the row-wise writes and the column-wise reads are bank-conflict free).  The pair's
+// two float64 power rows then alias the exchange area, and the band-sparse mel sums + logarithm read them from there.
+// Everything between PCM and log-mel is wave-local: no workgroup barrier inside an item.
+//
+// 40 KB of LDS and <= 128 VGPRs: four workgroups (16 waves) per CU, which is what hides the LDS round trips and the
+// PCM latency (at two workgroups per CU the same arithmetic took 0.235 ms instead of 0.1x ms).
+// =====================================================================================================================
+namespace kaldi64 {
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int kTileFrames = 32;
+constexpr int kFramesPerWave = 8;
+constexpr int kHop = 160;
+constexpr int kFrame = 400;
+constexpr int kPowStride = 258;            // doubles per power row (257 bins)
+constexpr int kMaxBandWeights = 520;       // a triangular bank over 257 bins has at most 2 non-zero weights per bin
+constexpr int kLogEntries = 64;
+constexpr int kWgPerCu = 3;
+constexpr int kExchBytes = 8192;           // per wave: 512 complex doubles
+constexpr int kTw2Off = kWaves * kExchBytes;            // 64 x complex double: W64^(j q) at [q][j]
+constexpr int kBandOff = kTw2Off + 64 * 16;             // 128 x {first bin | bins << 16, weight offset}
+constexpr int kWtsOff = kBandOff + 128 * 8;             // float64 band weights
+constexpr int kLogOff = kWtsOff + kMaxBandWeights * 8;  // 64 x {1 / c, ln c}
+constexpr int kLdsBytes = kLogOff + kLogEntries * 16;
+static_assert(kLdsBytes + 16 <= 40960, "four workgroups per CU");
+static_assert(2 * kPowStride * 8 <= kExchBytes, "a pair's two power rows alias the wave's exchange area");
+}  // namespace kaldi64
+
+struct cd {
+    double x, y;
+};
+typedef int int2k __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cd operator+(cd a, cd b) { return cd{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cd operator-(cd a, cd b) { return cd{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cd cmuld(cd a, cd b) { return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ void dft4d(cd& a0, cd& a1, cd& a2, cd& a3) {
+    const cd s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+    a0 = s02 + s13;
+    a2 = s02 - s13;
+    a1 = cd{d02.x + d13.y, d02.y - d13.x};      // d02 - i d13
+    a3 = cd{d02.x - d13.y, d02.y + d13.x};      // d02 + i d13
+}
+// 8-point forward DFT in place, natural order in / out (2 x 4 Cooley-Tukey, as dft8 of fft_core.h)
+__device__ __forceinline__ void dft8d(cd (&v)[8]) {
+    constexpr double kH = 0.70710678118654752440;
+    cd e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    cd o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    dft4d(e0, e1, e2, e3);
+    dft4d(o0, o1, o2, o3);
+    const cd w1{(o1.x + o1.y) * kH, (o1.y - o1.x) * kH};       // * (1 - i) / sqrt 2
+    const cd w2{o2.y, -o2.x};                                  // * -i
+    const cd w3{(o3.y - o3.x) * kH, -(o3.x + o3.y) * kH};      // * (-1 - i) / sqrt 2
+    v[0] = e0 + o0;
+    v[4] = e0 - o0;
+    v[1] = e1 + w1;
+    v[5] = e1 - w1;
+    v[2] = e2 + w2;
+    v[6] = e2 - w2;
+    v[3] = e3 + w3;
+    v[7] = e3 - w3;
+}
+// ln x for a normal x > 0 with an absolute error of a few 1e-16 (the caller rounds the result to float32, whose ulp at
+// the |ln| <= 30 of mel energies is >= 1e-10 apart from results next to 0): x = 2^e m, m in [1, 2), c = the centre of
+// m's 1/64-wide interval, r = m / c - 1 (|r| <= 2^-7), ln x = e ln 2 + ln c + log1p(r) with log1p to r^7
+// (the next term is < 2e-18).  Fifteen float64 instructions instead of the library routine's ~100.
+__device__ __forceinline__ double log_tab64(double x, const double2k* __restrict__ ltab) {
+    const long long bits = __double_as_longlong(x);
+    const int hi = (int)(bits >> 32);
+    const int e = (hi >> 20) - 1023;
+    const double m = __longlong_as_double((bits & 0x000FFFFFFFFFFFFFll) | 0x3FF0000000000000ll);
+    const double2k t = ltab[(hi >> 14) & (kaldi64::kLogEntries - 1)];
+    const double r = fma(m, t.x, -1.0);
+    double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
+    p = fma(r, p, 0.2);
+    p = fma(r, p, -0.25);
+    p = fma(r, p, 1.0 / 3.0);
+    p = fma(r, p, -0.5);
+    p = fma(r, p, 1.0);
+    return fma(r, p, fma((double)e, 0.693147180559945309417, t.y));
+}
+// sum of a float64 over the wave, the same value in every lane: rotations inside the rows of 16 lanes (DPP), then the
+// four row sums through scalar registers -- no LDS traffic, unlike the shuffle form
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    auto ror = [](double a, auto ctrl) {
+        const long long b = __double_as_longlong(a);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)b, decltype(ctrl)::value, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), decltype(ctrl)::value, 0xf, 0xf, false);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+    };
+    v += ror(v, std::integral_constant<int, 0x128>{});      // row_ror:8
+    v += ror(v, std::integral_constant<int, 0x124>{});      // row_ror:4
+    v += ror(v, std::integral_constant<int, 0x122>{});      // row_ror:2
+    v += ror(v, std::integral_constant<int, 0x121>{});      // row_ror:1
+    auto row = [&](int l) {
+        const long long b = __double_as_longlong(v);
+        const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+    };
+    return (row(0) + row(16)) + (row(32) + row(48));
+}
+
+__global__ __launch_bounds__(kaldi64::kThreads, kaldi64::kWgPerCu) void kaldi_fbank64_kernel(
+    const float* __restrict__ pcm, const int64_t* __restrict__ offsets,
+    const int32_t* __restrict__ lengths, int n_mels, int t_max, int max_frames,
+    const KaldiTablesHeader* __restrict__ tab, float* __restrict__ out,
+    int tiles_per_block, int n_runs, int n_items, unsigned* __restrict__ ticket) {
+    using namespace kaldi64;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsBytes];
+    __shared__ unsigned s_next[2];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int item = blockIdx.x;
+    if (item >= n_items) return;
+    if (tab->magic != kKaldiMagic || tab->n_mels != n_mels) return;      // the CMVN pass poisons the output
+
+    // float64 section of the tables blob: window[400], W512 (cos, -sin)[512], then the mel bands and their weights
+    const double* __restrict__ t64 = reinterpret_cast<const double*>(
+        reinterpret_cast<const char*>(tab + 1) + (((size_t)tab->afrag_floats * 4 + 7) & ~(size_t)7));
+    const double* __restrict__ w512 = t64 + kFrame;
+    double win64[7];
+#pragma unroll
+    for (int m = 0; m < 7; ++m) win64[m] = (lane + 64 * m < kFrame) ? t64[lane + 64 * m] : 0.0;
+    {
+        const int nm = min(n_mels, 128);
+        const int4k* __restrict__ bg = reinterpret_cast<const int4k*>(t64 + kFrame + 1024);
+        const double* __restrict__ wg = t64 + kFrame + 1024 + 2 * nm;
+        int2k* bl = reinterpret_cast<int2k*>(smem + kBandOff);
+        double* wl = reinterpret_cast<double*>(smem + kWtsOff);
+        for (int i = tid; i < nm; i += kThreads) {
+            const int4k b = bg[i];
+            bl[i] = int2k{b.x | (b.y << 16), b.z};
+        }
+        const int nw = min(tab->reserved, kMaxBandWeights);
+        for (int i = tid; i < nw; i += kThreads) wl[i] = wg[i];
+        if (tid < 64) {
+            const int i2 = (8 * (tid & 7) * (tid >> 3)) & 511;            // [q][j]: W512^(8 j q)
+            reinterpret_cast<cd*>(smem + kTw2Off)[tid] = cd{w512[2 * i2], w512[2 * i2 + 1]};
+        } else if (tid < 64 + kLogEntries) {
+            const double c = 1.0 + ((double)(tid - 64) + 0.5) * (1.0 / kLogEntries);
+            reinterpret_cast<double2k*>(smem + kLogOff)[tid - 64] = double2k{1.0 / c, log(c)};
+        }
+        __syncthreads();
+    }
+    cd* exch = reinterpret_cast<cd*>(smem + wave * kExchBytes);
+    double* pp = reinterpret_cast<double*>(exch);
+    const cd* tw2 = reinterpret_cast<const cd*>(smem + kTw2Off) + (lane & 7);
+    const int2k* band64 = reinterpret_cast<const int2k*>(smem + kBandOff);
+    const double* wts64 = reinterpret_cast<const double*>(smem + kWtsOff);
+    const double2k* ltab = reinterpret_cast<const double2k*>(smem + kLogOff);
+    const int mel_rounds = (2 * n_mels + 63) >> 6;
+
+    unsigned iter = 0;
+    while (item < n_items) {
+        unsigned my_ticket = 0;
+        if (tid == 0) my_ticket = atomicAdd(ticket, 1u);           // the workgroup's next item, needed at the end of this one
+        const int clip = __builtin_amdgcn_readfirstlane(item / n_runs), run = item - clip * n_runs;
+        const int n_valid = __builtin_amdgcn_readfirstlane(lengths[clip]);
+        const float* __restrict__ x;
+        {
+            const int64_t o = offsets[clip];
+            x = pcm + (((int64_t)__builtin_amdgcn_readfirstlane((int)(o >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)o));
+        }
+        const int T = kaldi_num_frames(n_valid, max_frames, t_max);
+        // this wave's frames of the run: 8 per tile
+        const int f_first = run * tiles_per_block * kTileFrames + wave * kFramesPerWave;
+        const int f_run_end = min((run + 1) * tiles_per_block * kTileFrames, T);
+        float* __restrict__ out_clip = out + (size_t)clip * t_max * n_mels;
+
+        // samples x[n], x[n - 1] of the pair's two frames for n = lane + 64 m (frame b starts one hop later)
+        float xa[7], xp[7], xb[7], xq[7];
+        auto load_pair = [&](int fa) {
+            const int base0 = kHop * fa;
+            const int base = base0 + lane;
+            if (base0 + kHop + kFrame <= n_valid) {                   // both frames inside the clip: no per-sample bounds
+#pragma unroll
+                for (int m = 0; m < 6; ++m) {
+                    const int ia = base + 64 * m, ib = ia + kHop;
+                    xa[m] = x[ia];
+                    xp[m] = x[ia > 0 ? ia - 1 : 0];                   // (lane 0, m 0) is never used: buffer[0] *= 0.03
+                    xb[m] = x[ib];
+                    xq[m] = x[ib - 1];
+                }
+                xa[6] = xp[6] = xb[6] = xq[6] = 0.0f;
+                if (lane < kFrame - 6 * 64) {
+                    const int ia = base + 64 * 6, ib = ia + kHop;
+                    xa[6] = x[ia];
+                    xp[6] = x[ia - 1];
+                    xb[6] = x[ib];
+                    xq[6] = x[ib - 1];
+                }
+                return;
+            }
+#pragma unroll
+            for (int m = 0; m < 7; ++m) {
+                const int ia = base + 64 * m, ib = ia + kHop;
+                const bool in_frame = lane + 64 * m < kFrame;
+                xa[m] = (in_frame && ia < n_valid) ? x[ia] : 0.0f;
+                xp[m] = (in_frame && ia < n_valid && ia > 0) ? x[ia - 1] : 0.0f;
+                xb[m] = (in_frame && ib < n_valid) ? x[ib] : 0.0f;
+                xq[m] = (in_frame && ib < n_valid) ? x[ib - 1] : 0.0f;
+            }
+        };
+        // frame index of the wave's j-th pair of the run
+        auto pair_frame = [&](int j) { return f_first + (j >> 2) * kTileFrames + 2 * (j & 3); };
+        int j = 0;
+        int fa = pair_frame(0);
+        if (fa < f_run_end) load_pair(fa);
+        while (fa < f_run_end) {
+            // per-frame mean over the 400 samples (HF:audio_utils.py:979-980), float64
+            double sa = 0.0, sb = 0.0;
+#pragma unroll
+            for (int m = 0; m < 7; ++m) {
+                sa += (double)xa[m];
+                sb += (double)xb[m];
+            }
+            const double mu_a = wave_sum_f64(sa) / 400.0, mu_b = wave_sum_f64(sb) / 400.0;
+            cd v[8];
+#pragma unroll
+            for (int m = 0; m < 7; ++m) {
+                // buffer - mean; buffer[1:] -= 0.97 buffer[:-1]; buffer[0] *= 1 - 0.97; * window (:979-986)
+                const double da = (double)xa[m] - mu_a, db = (double)xb[m] - mu_b;
+                double ea = da - 0.97 * ((double)xp[m] - mu_a);
+                double eb = db - 0.97 * ((double)xq[m] - mu_b);
+                if (m == 0 && lane == 0) {
+                    ea = da * (1.0 - 0.97);
+                    eb = db * (1.0 - 0.97);
+                }
+                v[m] = cd{ea * win64[m], eb * win64[m]};              // win64 is 0 past the frame
+            }
+            v[7] = cd{0.0, 0.0};
+            // first-pass twiddles W512^(l q) from the table in global memory (8 KB, L1 resident), requested BEFORE
+            // the next pair's PCM so that waiting for them does not wait for HBM
+            cd tw1[8];
+            int lane_o = lane;                                        // opaque per pair: keeps the (loop-invariant) twiddle
+            asm volatile("" : "+v"(lane_o));                          // loads inside the loop instead of 60 registers
+#pragma unroll
+            for (int q = 1; q < 8; ++q) {
+                const int i1 = (lane_o * q) & 511;
+                const double2k w = *reinterpret_cast<const double2k*>(w512 + 2 * i1);
+                tw1[q] = cd{w.x, w.y};
+            }
+            const int fa_next = pair_frame(j + 1);
+            if (fa_next < f_run_end) load_pair(fa_next);              // lands in the registers the window stage just freed
+            dft8d(v);                                                 // over m: Y_l[q]
+            wave_lds_sync2();                                         // after the previous pair's mel reads
+            {
+                cd* row = exch + lane * 8;
+                const int sw = lane & 7;
+                row[sw] = v[0];
+#pragma unroll
+                for (int q = 1; q < 8; ++q) row[q ^ sw] = cmuld(v[q], tw1[q]);
+            }
+            wave_lds_sync2();
+            {
+                const int l0 = lane & 7, q2 = lane >> 3;              // lane = l0 + 8 q: rows l0 + 8 l1, column q
+                const cd* col = exch + l0 * 8 + (q2 ^ l0);
+                cd t2[8];
+#pragma unroll
+                for (int s2 = 1; s2 < 8; ++s2) t2[s2] = tw2[8 * s2 + (lane_o - lane)];
+#pragma unroll
+                for (int l1 = 0; l1 < 8; ++l1) v[l1] = col[64 * l1];
+                wave_lds_sync2();
+                dft8d(v);                                             // over l1: U[l0][s][q]
+                cd* dst = exch + q2 * 64;
+                const int sw = l0 ^ q2;
+                dst[sw] = v[0];
+#pragma unroll
+                for (int s2 = 1; s2 < 8; ++s2) dst[s2 * 8 + (sw ^ s2)] = cmuld(v[s2], t2[s2]);
+            }
+            wave_lds_sync2();
+            {
+                const int q3 = lane & 7, s3 = lane >> 3;              // lane = q + 8 s = bin index mod 64
+                const cd* src = exch + q3 * 64 + s3 * 8;
+                const int sw = s3 ^ q3;
+#pragma unroll
+                for (int l0 = 0; l0 < 8; ++l0) v[l0] = src[l0 ^ sw];
+                dft8d(v);                                             // over l0: v[t] = Z[lane + 64 t]
+            }
+            wave_lds_sync2();                                         // the power rows overwrite the exchange area
+            // spectra of the two real frames: A[k] = (Z[k] + conj Z[512 - k]) / 2, B[k] = (Z[k] - conj Z[512 - k]) / 2i,
+            // each rounded to complex64 as HF stores them (:966, :988), then |.|^2 (the 1/4 is in the mel bank)
+            {
+                const int partner = (64 - lane) & 63;
+                double* prow = pp + lane;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    double qr = __shfl(v[7 - t].x, partner, 64);
+                    double qi = __shfl(v[7 - t].y, partner, 64);
+                    if (lane == 0) {
+                        qr = v[(8 - t) & 7].x;
+                        qi = v[(8 - t) & 7].y;
+                    }
+                    const double sr = (double)(float)(v[t].x + qr), dr = (double)(float)(v[t].x - qr);
+                    const double si = (double)(float)(v[t].y + qi), di = (double)(float)(v[t].y - qi);
+                    prow[64 * t] = sr * sr + di * di;                 // np.abs(complex64, dtype=float64) ** 2 (:993)
+                    prow[kPowStride + 64 * t] = si * si + dr * dr;
+                }
+                if (lane == 0) {                                      // bin 256
+                    const double ar = (double)(float)(2.0 * v[4].x), br = (double)(float)(2.0 * v[4].y);
+                    prow[256] = ar * ar;
+                    prow[kPowStride + 256] = br * br;
+                }
+            }
+            wave_lds_sync2();
+            // mel projection and log in float64, rounded to float32 once (:998-1015): lane pairs = (mel bin, frame a | b),
+            // widest bands first so that the lanes of a round have bands of similar length
+            for (int r = 0; r < mel_rounds; ++r) {
+                const int o = lane + 64 * r;
+                const int mel = n_mels - 1 - (o >> 1), fr = o & 1;
+                if (mel >= 0) {
+                    const int2k b = band64[mel];
+                    const int k0 = b.x & 0xffff, cnt = b.x >> 16;
+                    const double* w = wts64 + b.y;
+                    const double* pr = pp + fr * kPowStride + k0;
+                    double acc = 0.0;
+                    int jj = 0;
+                    for (; jj + 4 <= cnt; jj += 4) {
+                        const double w0 = w[jj], w1 = w[jj + 1], w2 = w[jj + 2], w3 = w[jj + 3];
+                        const double p0 = pr[jj], p1 = pr[jj + 1], p2 = pr[jj + 2], p3 = pr[jj + 3];
+                        acc += w0 * p0;
+                        acc += w1 * p1;
+                        acc += w2 * p2;
+                        acc += w3 * p3;
+                    }
+                    for (; jj < cnt; ++jj) acc += w[jj] * pr[jj];
+                    const int t = fa + fr;
+                    if (t < T) out_clip[(unsigned)(t * n_mels + mel)] = (float)log_tab64(fmax(acc, 1.192092955078125e-07), ltab);
+                }
+            }
+            ++j;
+            fa = fa_next;
+        }
+        // hand-over of the next item through one of two alternating LDS slots (a slot is rewritten only after the
+        // barrier of the following item, which every thread reaches after this read)
+        if (tid == 0) s_next[iter & 1u] = my_ticket + gridDim.x;
+        __syncthreads();
+        item = (int)min(s_next[iter & 1u], (unsigned)n_items);
+        ++iter;
+    }
 }
 
 // float64 mode: per-clip per-bin mean and standard deviation exactly as HF's utterance_cmvn computes them
@@ -778,12 +919,15 @@ extern "C" int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, 
     unsigned* ticket = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + need - 256);
     {
         ScopedTiming t(kTimeKaldiFbank, stream);
-        if (flags & STTFE_KALDI_F64)
-            hipLaunchKernelGGL(kaldi_fbank_kernel<true>, dim3(grid), dim3(kaldi::kThreads), 0, stream, pcm, offsets,
+        if (flags & STTFE_KALDI_F64) {
+            const int res64 = kaldi64::kWgPerCu * current_device_cus();
+            const int grid64 = n_items < res64 ? n_items : res64;
+            hipLaunchKernelGGL(kaldi_fbank64_kernel, dim3(grid64), dim3(kaldi64::kThreads), 0, stream, pcm, offsets,
+                               lengths, n_mels, t_max, max_frames, tab, out, tiles_per_block, n_runs, n_items, ticket);
+        } else {
+            hipLaunchKernelGGL(kaldi_fbank_kernel, dim3(grid), dim3(kaldi::kThreads), 0, stream, pcm, offsets,
                                lengths, n_mels, t_max, max_frames, tab, out, stats, tiles_per_block, n_runs, n_items, ticket);
-        else
-            hipLaunchKernelGGL(kaldi_fbank_kernel<false>, dim3(grid), dim3(kaldi::kThreads), 0, stream, pcm, offsets,
-                               lengths, n_mels, t_max, max_frames, tab, out, stats, tiles_per_block, n_runs, n_items, ticket);
+        }
     }
     {
         ScopedTiming t(kTimeKaldiCmvn, stream);
