@@ -61,6 +61,7 @@ constexpr float kMelFloor = 1.1920928955078125e-07f;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int int4k __attribute__((ext_vector_type(4)));
 typedef double double2k __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void wave_lds_sync2() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -866,6 +867,123 @@ __global__ __launch_bounds__(256) void kaldi_cmvn_kernel(
     }
 }
 
+// float64 mode, fused form of the two kernels above for the common shapes (n_mels a multiple of G, a clip's G columns
+// fit in LDS): a workgroup owns G mel columns of one clip, reads them ONCE into an LDS panel [t][G], lanes 0..G-1 run
+// the three sequential float32 passes of kaldi_stats_seq_kernel on the panel (same additions in the same order), and
+// all threads then normalise the panel into the output (masks, zero padding and the attention mask as in
+// kaldi_cmvn_kernel).  One read and one write of the features instead of four reads and one write.
+template <int G>
+__global__ __launch_bounds__(256) void kaldi_cmvn_seq_kernel(
+    float* __restrict__ out, const int32_t* __restrict__ lengths, int batch, int n_mels, int t_max, int max_frames,
+    void* __restrict__ attn, int attn_bytes, const int32_t* __restrict__ mask_tbl, int n_masks,
+    const KaldiTablesHeader* __restrict__ tab) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) float panel[];      // [T][G]
+    __shared__ float s_mean[G], s_std[G];
+    constexpr int Q = G / 4;                                            // float4 groups per panel row
+    // workgroup -> (clip, column group): consecutive workgroup ids go round the 8 XCDs, so the groups of ONE clip are
+    // given ids 8 apart -- they run at the same time on the same XCD and the G-float pieces they read from and write
+    // to each output row meet in one L2.  (Measured neutral on config 2, 0.072 ms either way: the kernel's load, chain
+    // and store phases add up -- 0.031 + 0.017 + 0.025 ms when timed apart -- see DESIGN.md.)
+    const int tid = threadIdx.x, n_groups = n_mels / G;
+    const int slot = blockIdx.x >> 3, clip = (slot / n_groups) * 8 + (blockIdx.x & 7);
+    if (clip >= batch) return;
+    const int g0 = (slot % n_groups) * G;
+    float* __restrict__ o = out + (size_t)clip * t_max * n_mels + g0;
+    if (tab->magic != kKaldiMagic || tab->n_mels != n_mels) {
+        // tables built for another extractor: NaN everywhere instead of uninitialised memory (see sttfe.h)
+        for (int i = tid; i < t_max * G; i += 256) o[(size_t)(i / G) * n_mels + (i % G)] = __builtin_nanf("");
+        return;
+    }
+    const int T = kaldi_num_frames(lengths[clip], max_frames, t_max);
+    for (int base = tid; base < T * Q; base += 8 * 256) {               // eight loads in flight per thread
+        float4 r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = base + 256 * k, t = i / Q, c = i - t * Q;
+            if (i < T * Q) r[k] = *reinterpret_cast<const float4*>(o + (size_t)t * n_mels + 4 * c);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = base + 256 * k;
+            if (i < T * Q) reinterpret_cast<float4*>(panel)[i] = r[k];
+        }
+    }
+    __syncthreads();
+    // the chain runs in ONE wave of the workgroup; which one rotates with the workgroup index, so that the chains of
+    // the workgroups that share a CU land on different SIMDs instead of queueing on the first
+    const int chain_tid = tid - 64 * (slot & 3);
+    if (chain_tid >= 0 && chain_tid < G) {
+        const float* col = panel + chain_tid;
+        // 32 rows per block: the terms of two rows at a time in packed float32 (independent of the chain, IEEE per
+        // component), then the chain's 32 dependent additions in row order
+        auto sweep = [&](auto&& term) {
+            float acc = 0.0f;
+            int t = 0;
+            for (; t + 32 <= T; t += 32) {
+                f32x2 v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = term(f32x2{col[(t + 2 * i) * G], col[(t + 2 * i + 1) * G]});
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    acc = acc + v[i].x;
+                    acc = acc + v[i].y;
+                }
+            }
+            for (; t < T; ++t) acc = acc + term(f32x2{col[t * G], 0.0f}).x;
+            return acc;
+        };
+        float mean = 0.0f, sd = 1.0f;
+        if (T > 0) {
+            const float fT = (float)T;
+            mean = sweep([](f32x2 x) { return x; }) / fT;                                  // x.mean(axis=0)
+            const float arrmean = sweep([mean](f32x2 x) { return x - mean; }) / fT;        // _var: mean of x - mean
+            const float ssq = sweep([mean, arrmean](f32x2 x) {
+                const f32x2 d = (x - mean) - arrmean;
+                return d * d;
+            });
+            sd = sqrtf(ssq / fT);
+        }
+        s_mean[chain_tid] = mean;
+        s_std[chain_tid] = sd;
+    }
+    __syncthreads();
+    int m_axis[STTFE_MAX_MASKS], m_s[STTFE_MAX_MASKS], m_e[STTFE_MAX_MASKS];
+    const int nm = mask_tbl ? (n_masks > STTFE_MAX_MASKS ? STTFE_MAX_MASKS : n_masks) : 0;
+    for (int i = 0; i < nm; ++i) {
+        const int32_t* m = mask_tbl + ((size_t)clip * n_masks + i) * 3;
+        m_axis[i] = m[0];
+        m_s[i] = m[1];
+        m_e[i] = m[2];
+    }
+    auto norm = [&](float x, int t, int c) {
+        float y = (x - s_mean[c]) / s_std[c];
+        for (int i = 0; i < nm; ++i) {
+            const int idx = (m_axis[i] == STTFE_AXIS_TIME) ? t : g0 + c;
+            if (idx >= m_s[i] && idx < m_e[i]) y = 0.0f;
+        }
+        return y;
+    };
+    for (int i = tid; i < t_max * Q; i += 256) {
+        const int t = i / Q, c = (i - t * Q) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < T) {
+            v = reinterpret_cast<const float4*>(panel)[i];
+            v.x = norm(v.x, t, c);
+            v.y = norm(v.y, t, c + 1);
+            v.z = norm(v.z, t, c + 2);
+            v.w = norm(v.w, t, c + 3);
+        }
+        *reinterpret_cast<float4*>(o + (size_t)t * n_mels + c) = v;
+    }
+    if (attn && g0 == 0) {
+        for (int t = tid; t < t_max; t += 256) {
+            if (attn_bytes == 8) reinterpret_cast<int64_t*>(attn)[(size_t)clip * t_max + t] = t < T ? 1 : 0;
+            else reinterpret_cast<int32_t*>(attn)[(size_t)clip * t_max + t] = t < T ? 1 : 0;
+        }
+    }
+}
+
 }  // namespace sttfe
 
 using namespace sttfe;
@@ -931,13 +1049,24 @@ extern "C" int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, 
     }
     {
         ScopedTiming t(kTimeKaldiCmvn, stream);
-        if ((flags & STTFE_KALDI_F64) && !(flags & STTFE_KALDI_NO_CMVN))
-            hipLaunchKernelGGL(kaldi_stats_seq_kernel, dim3((batch * n_mels + 63) / 64), dim3(64), 0, stream, out, lengths,
-                               reinterpret_cast<float*>(workspace), batch, n_mels, t_max, max_frames);
-        int cx = (t_max * n_mels + 255) / 256;
-        if (cx > 64) cx = 64;
-        hipLaunchKernelGGL(kaldi_cmvn_kernel, dim3(cx, batch), dim3(256), 0, stream, out, lengths, stats, n_mels,
-                           t_max, max_frames, flags, attn_mask, attn_mask_bytes, mask_tbl, n_masks, tab);
+        constexpr int kG = 8;      // columns per workgroup: 4 -> 0.127, 8 -> 0.072, 16 -> 0.078 ms (config 2)
+        const bool seq_split = getenv("STTFE_KALDI_SPLIT_CMVN") != nullptr;     // A/B and test knob: the two-kernel form
+        const size_t panel_bytes = (size_t)t_max * kG * sizeof(float);
+        const bool f64_cmvn = (flags & STTFE_KALDI_F64) && !(flags & STTFE_KALDI_NO_CMVN);
+        if (f64_cmvn && !seq_split && n_mels % kG == 0 && panel_bytes <= 64 * 1024 &&
+            (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+            hipLaunchKernelGGL(kaldi_cmvn_seq_kernel<kG>, dim3((batch + 7) / 8 * 8 * (n_mels / kG)), dim3(256), panel_bytes,
+                               stream, out, lengths, batch, n_mels, t_max, max_frames, attn_mask, attn_mask_bytes,
+                               mask_tbl, n_masks, tab);
+        } else {
+            if (f64_cmvn)
+                hipLaunchKernelGGL(kaldi_stats_seq_kernel, dim3((batch * n_mels + 63) / 64), dim3(64), 0, stream, out,
+                                   lengths, reinterpret_cast<float*>(workspace), batch, n_mels, t_max, max_frames);
+            int cx = (t_max * n_mels + 255) / 256;
+            if (cx > 64) cx = 64;
+            hipLaunchKernelGGL(kaldi_cmvn_kernel, dim3(cx, batch), dim3(256), 0, stream, out, lengths, stats, n_mels,
+                               t_max, max_frames, flags, attn_mask, attn_mask_bytes, mask_tbl, n_masks, tab);
+        }
     }
     if (hip_failed(hipGetLastError(), "kaldi kernel launch")) return STTFE_E_LAUNCH;
     return STTFE_OK;

@@ -212,3 +212,23 @@ def test_cmvn_property_full_batch(fe):
     var = ((f - mean.unsqueeze(1)) ** 2 * m).sum(dim=1) / n
     assert float(mean.abs().max()) < 1e-4 and float((var - 1).abs().max()) < 1e-3
     assert float((f * (1 - m)).abs().max()) == 0.0
+
+
+def test_fused_and_split_cmvn_are_bit_identical_and_long_clips(fe, monkeypatch):
+    """float64 mode normalises through one fused kernel (a clip's columns in LDS) when the shapes allow it and through
+    the statistics + normalisation kernel pair otherwise (here: forced by the A/B knob, and a 27 s clip whose columns do
+    not fit): same additions in the same order, so the outputs are bit-identical; the long clip is checked against the
+    oracle."""
+    from oracle.kaldi import speech2text_features
+    clips = synth_batch(77, [48000, 123457, 16000, 400, 399])
+    a = fe(clips, sampling_rate=16000).input_features.cpu()
+    monkeypatch.setenv("STTFE_KALDI_SPLIT_CMVN", "1")
+    b = fe(clips, sampling_rate=16000).input_features.cpu()
+    monkeypatch.delenv("STTFE_KALDI_SPLIT_CMVN")
+    assert bool(((a == b) | (a.isnan() & b.isnan())).all())           # the one-frame clip has std 0: NaN, as in HF
+    assert not a[:3].isnan().any()
+    long_clip = synth_batch(78, [432000])                            # 2698 frames: beyond the fused kernel's panel
+    got = fe(long_clip, sampling_rate=16000).input_features.cpu().numpy()
+    exp, _, tl = speech2text_features(long_clip)
+    assert got.shape == exp.shape and tl[0] == 2698
+    assert float(np.abs(got - exp).max()) <= TOL
