@@ -347,7 +347,7 @@ def main():
     else:
         fe = HipSpeech2TextFeatureExtractor(device=device, stft_precision="float32" if s2t_f32 else "float64")
         t_max = max(fe.num_frames(n) for n in host_lens)
-        kernel, kname = "kaldi_fbank", "kaldi_fbank_kernel"
+        kernel, kname = "kaldi_fbank", ("kaldi_fbank_kernel" if s2t_f32 else "kaldi_fbank64_kernel")
         extra_kernels = ["kaldi_cmvn"]
         bytes_per_launch = float(4 * lens.sum() + (4 * 80 + 4) * t_max * B)
         step = lambda: fe.extract(pcm, offsets, lengths, t_max)

@@ -20,6 +20,10 @@
 //     log-mel stored; per-clip per-bin sum / sum of squares accumulated with f64 atomics.
 // Kernel 2 (kaldi_cmvn): (x - mean) / std per clip and bin over the valid frames, padded rows <- 0,
 //   SpecAugment masks <- 0, attention mask written (int32 or int64).
+// STTFE_KALDI_F64 (the default of HipSpeech2TextFeatureExtractor): the same result computed the way HF's NumPy path
+//   computes it -- float64 framing / window / transform, complex64 rounding, float64 mel + log (kaldi_fbank64_kernel),
+//   and NumPy-order float32 CMVN statistics (kaldi_cmvn_seq_kernel, or kaldi_stats_seq_kernel + kaldi_cmvn_kernel for
+//   shapes the fused kernel does not take); bit-identical to the HF goldens, see the comments at those kernels.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

@@ -5,28 +5,32 @@
 // (HF:models/whisper/feature_extraction_whisper.py:135-168) as reached from the reference at
 // src/data.py:338-343, inference.py:148-152 and src/processors.py:180-221.
 //
-// Kernel 1 (stft_mel): 256-thread workgroups (4 waves), three per CU (45 KB LDS, <= 168 VGPRs each).
-//   A workgroup walks a run of consecutive 48-frame tiles of one clip.  Per tile:
+// Kernel 1 (stft_mel): persistent 256-thread workgroups (4 waves, 253 VGPRs, 65 KB LDS -> two per CU, grid = 2 x CUs).
+//   A workgroup stages window, twiddles, mel weights and the unit plan in LDS once and then takes work items --
+//   (run of consecutive 48-frame tiles, clip) -- from a ticket counter in the workspace; ticket, length / offset and
+//   the first PCM tile of the next item are requested one to two items ahead.  Per tile:
 //   * every wave makes two passes of 3 frame pairs (12 frames).  Two real frames a, b are packed as
 //     z = a + i b and transformed by ONE complex 400-point DFT, factored 20 x 20: lane (p, j) of a pair
-//     runs a register-resident 20-point DFT over n1 of z[20 n1 + j] (fft_core.h, twiddle-free 4 x 5
-//     prime-factor form), multiplies by W_400^(j k1) (table in LDS), exchanges through a wave-private,
-//     bank-conflict-free LDS slab ([pair][k1][n2], row stride 21, pair stride 420 float2) and runs the
-//     second 20-point DFT over n2.  Lane j then holds Z[j + 20 k2]; the spectra of a and b are
-//     separated with one cross-lane exchange (lane j <-> lane 20 - j), bins 0..200 kept.
-//     The PCM of the NEXT pass is loaded into registers at the start of each pass, so a full pass of
-//     arithmetic hides the HBM latency; the window column lives in registers.
-//   * |A|^2, |B|^2 of both passes stay in registers until the wave's last slab read, then go to the
-//     wave's own 12 rows of the [frame][bin] power panel (row stride 204 floats), which aliases the
-//     wave's own slab: no workgroup barrier between FFT and panel.
+//     runs a register-resident 20-point DFT over n1 of z[20 n1 + j] (twiddle-free 4 x 5 prime-factor form in the
+//     packed-float32 forms of fft_pk.h), multiplies by W_400^(j k1) (the lane's twiddles stay in registers),
+//     exchanges through a wave-private LDS slab ([pair][k1][n2], row stride 22 complex: b64 writes, ten
+//     conflict-free b128 reads per lane) and runs the second 20-point DFT over n2.  Lane j then holds
+//     Z[j + 20 k2]; the spectra of a and b are separated with one cross-lane exchange (lane j <-> lane 20 - j),
+//     bins 0..200 kept.  The two passes are interleaved, so the arithmetic of one covers the LDS round trips of
+//     the other; the PCM of the next tile is requested right before the mel phase of the current one.
+//   * |A|^2, |B|^2 go to the wave's own 12 rows of the [frame][bin] power panel (row stride 204 floats), which
+//     aliases the wave's own slab: no workgroup barrier between FFT and panel.
 //   * barrier; banded mel projection on the matrix cores: exact-f32 v_mfma_f32_16x16x4_f32 tiles
 //     (16 mel rows x 16 frames) over only the bins each 16-row band of the triangular bank touches
-//     (53 k-steps for 80 mels, 56 for 128); (mel tile, frame tile) units are spread over the 4 waves
-//     by a host-built plan (tables.cpp); barrier.
+//     (60 k-steps for 80 mels, 68 for 128); operands as one b128 per lane and group of four k-steps.  The
+//     (mel tile, frame tile) units of a wave come from a plan: for the 80- and 128-bin extractors a compile-time
+//     copy of it (fully unrolled units, immediate-offset operand reads; taken for whole, unmasked tiles when the
+//     tables' plan matches), otherwise the host-built descriptors of tables.cpp; barrier.
 //   * epilogue: log10(max(mel, 1e-10)) -> (x + 4) / 4 stored unclamped with the SpecAugment masks
 //     applied from per-tile / per-clip bit masks; per-clip max and per-tile min of log10 go to the
 //     workspace with one atomic per wave.
-//   Tiles that lie entirely in the 30 s zero padding are left to kernel 2 (they are constant).
+//   Tiles that lie entirely in the padding are left to kernel 2 (they are constant).
+//   Three modes (kMode*): HF semantics, and the two of the reference's TorchWhisperFeatureExtractor.
 // Kernel 2 (clamp_fill): 16-32 workgroups per clip, each owning 4-5 interleaved mel rows.  The zero-padding region is filled
 //   with the final constant (write only); of the computed tiles only those whose recorded minimum is below
 //   max - 8 are re-read and clamped to (max - 8 + 4) / 4 (everything else is already final).
