@@ -412,8 +412,9 @@ constexpr int kTw2Off = kWaves * kExchBytes;            // 64 x complex double: 
 constexpr int kBandOff = kTw2Off + 64 * 16;             // 128 x {first bin | bins << 16, weight offset}
 constexpr int kWtsOff = kBandOff + 128 * 8;             // float64 band weights
 constexpr int kLogOff = kWtsOff + kMaxBandWeights * 8;  // 64 x {1 / c, ln c}
-constexpr int kLdsBytes = kLogOff + kLogEntries * 16;
-static_assert(kLdsBytes + 16 <= 40960, "four workgroups per CU");
+constexpr int kWinOff = kLogOff + kLogEntries * 16;     // float64 window, zero-padded to 448 entries
+constexpr int kLdsBytes = kWinOff + 448 * 8;
+static_assert(3 * (kLdsBytes + 16) <= 160 * 1024, "three workgroups per CU");
 static_assert(2 * kPowStride * 8 <= kExchBytes, "a pair's two power rows alias the wave's exchange area");
 }  // namespace kaldi64
 
@@ -474,8 +475,8 @@ __device__ __forceinline__ double log_tab64(double x, const double2k* __restrict
 __device__ __forceinline__ double wave_sum_f64(double v) {
     auto ror = [](double a, auto ctrl) {
         const long long b = __double_as_longlong(a);
-        const int lo = __builtin_amdgcn_update_dpp(0, (int)b, decltype(ctrl)::value, 0xf, 0xf, false);
-        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), decltype(ctrl)::value, 0xf, 0xf, false);
+        const int lo = __builtin_amdgcn_mov_dpp((int)b, decltype(ctrl)::value, 0xf, 0xf, false);      // every lane has a source:
+        const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), decltype(ctrl)::value, 0xf, 0xf, false);   // no "old" value to set up
         return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
     };
     v += ror(v, std::integral_constant<int, 0x128>{});      // row_ror:8
@@ -510,10 +511,8 @@ __global__ __launch_bounds__(kaldi64::kThreads, kaldi64::kWgPerCu) void kaldi_fb
     const double* __restrict__ t64 = reinterpret_cast<const double*>(
         reinterpret_cast<const char*>(tab + 1) + (((size_t)tab->afrag_floats * 4 + 7) & ~(size_t)7));
     const double* __restrict__ w512 = t64 + kFrame;
-    double win64[7];
-#pragma unroll
-    for (int m = 0; m < 7; ++m) win64[m] = (lane + 64 * m < kFrame) ? t64[lane + 64 * m] : 0.0;
     {
+        for (int i = tid; i < 448; i += kThreads) reinterpret_cast<double*>(smem + kWinOff)[i] = i < kFrame ? t64[i] : 0.0;
         const int nm = min(n_mels, 128);
         const int4k* __restrict__ bg = reinterpret_cast<const int4k*>(t64 + kFrame + 1024);
         const double* __restrict__ wg = t64 + kFrame + 1024 + 2 * nm;
@@ -560,46 +559,41 @@ __global__ __launch_bounds__(kaldi64::kThreads, kaldi64::kWgPerCu) void kaldi_fb
         const int f_run_end = min((run + 1) * tiles_per_block * kTileFrames, T);
         float* __restrict__ out_clip = out + (size_t)clip * t_max * n_mels;
 
-        // samples x[n], x[n - 1] of the pair's two frames for n = lane + 64 m (frame b starts one hop later)
-        float xa[7], xp[7], xb[7], xq[7];
-        auto load_pair = [&](int fa) {
-            const int base0 = kHop * fa;
-            const int base = base0 + lane;
-            if (base0 + kHop + kFrame <= n_valid) {                   // both frames inside the clip: no per-sample bounds
+        // samples x[n], x[n - 1] of the pair's two frames for n = lane + 64 m (frame b starts one hop later).  Frame a is
+        // a valid frame (fa < T), so all of its samples are inside the clip; frame b of an odd last pair is not: frame a
+        // is loaded again in its place (its results are not stored).  No per-sample bounds anywhere.
+        auto load_pair = [&](int fa, float (&xa)[7], float (&xp)[7], float (&xb)[7], float (&xq)[7]) {
+            const int hop_b = (fa + 1 < T) ? kHop : 0;                // wave-uniform
+            const int i0 = kHop * fa + lane;
+            const float* __restrict__ pa = x + i0;
+            const float* __restrict__ pb = pa + hop_b;
+            xa[0] = pa[0];
+            xb[0] = pb[0];
+            xp[0] = x[max(i0 - 1, 0)];                                // (lane 0, m 0) is never used: buffer[0] *= 0.03
+            xq[0] = x[max(i0 + hop_b - 1, 0)];
 #pragma unroll
-                for (int m = 0; m < 6; ++m) {
-                    const int ia = base + 64 * m, ib = ia + kHop;
-                    xa[m] = x[ia];
-                    xp[m] = x[ia > 0 ? ia - 1 : 0];                   // (lane 0, m 0) is never used: buffer[0] *= 0.03
-                    xb[m] = x[ib];
-                    xq[m] = x[ib - 1];
-                }
-                xa[6] = xp[6] = xb[6] = xq[6] = 0.0f;
-                if (lane < kFrame - 6 * 64) {
-                    const int ia = base + 64 * 6, ib = ia + kHop;
-                    xa[6] = x[ia];
-                    xp[6] = x[ia - 1];
-                    xb[6] = x[ib];
-                    xq[6] = x[ib - 1];
-                }
-                return;
+            for (int m = 1; m < 6; ++m) {
+                xa[m] = pa[64 * m];
+                xp[m] = pa[64 * m - 1];
+                xb[m] = pb[64 * m];
+                xq[m] = pb[64 * m - 1];
             }
-#pragma unroll
-            for (int m = 0; m < 7; ++m) {
-                const int ia = base + 64 * m, ib = ia + kHop;
-                const bool in_frame = lane + 64 * m < kFrame;
-                xa[m] = (in_frame && ia < n_valid) ? x[ia] : 0.0f;
-                xp[m] = (in_frame && ia < n_valid && ia > 0) ? x[ia - 1] : 0.0f;
-                xb[m] = (in_frame && ib < n_valid) ? x[ib] : 0.0f;
-                xq[m] = (in_frame && ib < n_valid) ? x[ib - 1] : 0.0f;
-            }
+            // m = 6: only lanes 0..15 are inside the frame; the others read a clamped (valid) address and drop the value
+            // -- a divergent block here makes the compiler wait for ALL of the loads at its end
+            const bool in6 = lane < kFrame - 6 * 64;
+            const int last = n_valid - 1;
+            const float a6 = x[min(i0 + 64 * 6, last)], p6 = x[min(i0 + 64 * 6 - 1, last)];
+            const float b6 = x[min(i0 + hop_b + 64 * 6, last)], q6 = x[min(i0 + hop_b + 64 * 6 - 1, last)];
+            xa[6] = in6 ? a6 : 0.0f;
+            xp[6] = in6 ? p6 : 0.0f;
+            xb[6] = in6 ? b6 : 0.0f;
+            xq[6] = in6 ? q6 : 0.0f;
         };
         // frame index of the wave's j-th pair of the run
         auto pair_frame = [&](int j) { return f_first + (j >> 2) * kTileFrames + 2 * (j & 3); };
-        int j = 0;
-        int fa = pair_frame(0);
-        if (fa < f_run_end) load_pair(fa);
-        while (fa < f_run_end) {
+        // one frame pair: window stage on (xa, xp, xb, xq), the NEXT pair's samples requested into (na, np, nb, nq)
+        auto do_pair = [&](int fa, int fa_next, const float (&xa)[7], const float (&xp)[7], const float (&xb)[7],
+                           const float (&xq)[7], float (&na)[7], float (&np)[7], float (&nb)[7], float (&nq)[7]) {
             // per-frame mean over the 400 samples (HF:audio_utils.py:979-980), float64
             double sa = 0.0, sb = 0.0;
 #pragma unroll
@@ -607,19 +601,27 @@ __global__ __launch_bounds__(kaldi64::kThreads, kaldi64::kWgPerCu) void kaldi_fb
                 sa += (double)xa[m];
                 sb += (double)xb[m];
             }
-            const double mu_a = wave_sum_f64(sa) / 400.0, mu_b = wave_sum_f64(sb) / 400.0;
+            const double mu_a = wave_sum_f64(sa) * (1.0 / 400.0), mu_b = wave_sum_f64(sb) * (1.0 / 400.0);   // (a multiply: 1e-16 from np.mean's division)
+            const double ca = (1.0 - 0.97) * mu_a, cb = (1.0 - 0.97) * mu_b;
             cd v[8];
+            // the lane's window column comes from LDS per pair (opaque offset: the compiler would otherwise keep the
+            // loop-invariant column in 14 registers, which this kernel does not have)
+            int lane_w = lane;
+            asm volatile("" : "+v"(lane_w));
+            const double* win64 = reinterpret_cast<const double*>(smem + kWinOff) + lane_w;
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
-                // buffer - mean; buffer[1:] -= 0.97 buffer[:-1]; buffer[0] *= 1 - 0.97; * window (:979-986)
-                const double da = (double)xa[m] - mu_a, db = (double)xb[m] - mu_b;
-                double ea = da - 0.97 * ((double)xp[m] - mu_a);
-                double eb = db - 0.97 * ((double)xq[m] - mu_b);
+                // buffer - mean; buffer[1:] -= 0.97 buffer[:-1]; buffer[0] *= 1 - 0.97; * window (:979-986);
+                // (x - mu) - 0.97 (x' - mu) is evaluated as (x - 0.97 x') - 0.03 mu: one operation less per sample, and
+                // 1e-16 relative away from HF's own float64 rounding, far below the complex64 rounding that follows
+                double ea = fma(-0.97, (double)xp[m], (double)xa[m]) - ca;
+                double eb = fma(-0.97, (double)xq[m], (double)xb[m]) - cb;
                 if (m == 0 && lane == 0) {
-                    ea = da * (1.0 - 0.97);
-                    eb = db * (1.0 - 0.97);
+                    ea = ((double)xa[m] - mu_a) * (1.0 - 0.97);
+                    eb = ((double)xb[m] - mu_b) * (1.0 - 0.97);
                 }
-                v[m] = cd{ea * win64[m], eb * win64[m]};              // win64 is 0 past the frame
+                const double wm = win64[64 * m];                      // 0 past the frame
+                v[m] = cd{ea * wm, eb * wm};
             }
             v[7] = cd{0.0, 0.0};
             // first-pass twiddles W512^(l q) from the table in global memory (8 KB, L1 resident), requested BEFORE
@@ -633,8 +635,9 @@ __global__ __launch_bounds__(kaldi64::kThreads, kaldi64::kWgPerCu) void kaldi_fb
                 const double2k w = *reinterpret_cast<const double2k*>(w512 + 2 * i1);
                 tw1[q] = cd{w.x, w.y};
             }
-            const int fa_next = pair_frame(j + 1);
-            if (fa_next < f_run_end) load_pair(fa_next);              // lands in the registers the window stage just freed
+            // unconditional (past the run's end the current, valid, pair is requested again and never used): a
+            // conditional block makes the compiler wait for the loads at its end to merge them into the loop registers
+            load_pair(fa_next < f_run_end ? fa_next : fa, na, np, nb, nq);
             dft8d(v);                                                 // over m: Y_l[q]
             wave_lds_sync2();                                         // after the previous pair's mel reads
             {
@@ -721,8 +724,19 @@ __global__ __launch_bounds__(kaldi64::kThreads, kaldi64::kWgPerCu) void kaldi_fb
                     if (t < T) out_clip[(unsigned)(t * n_mels + mel)] = (float)log_tab64(fmax(acc, 1.192092955078125e-07), ltab);
                 }
             }
-            ++j;
+        };
+        // one register set in the source: the next pair's samples are requested after the window stage has consumed
+        // this pair's (the compiler lands them in temporaries and copies at the end of the iteration; alternating two
+        // explicit sets instead spilled 17 loop-invariant LDS addresses and was slower, 0.231 vs 0.188 ms)
+        float xa0[7], xp0[7], xb0[7], xq0[7];
+        int j = 0;
+        int fa = pair_frame(0);
+        if (fa < f_run_end) load_pair(fa, xa0, xp0, xb0, xq0);
+        while (fa < f_run_end) {
+            const int fa_next = pair_frame(j + 1);
+            do_pair(fa, fa_next, xa0, xp0, xb0, xq0, xa0, xp0, xb0, xq0);
             fa = fa_next;
+            ++j;
         }
         // hand-over of the next item through one of two alternating LDS slots (a slot is rewritten only after the
         // barrier of the following item, which every thread reaches after this read)
