@@ -180,13 +180,17 @@ __device__ __forceinline__ bool plan_matches(const MelPlan& p) {
 }
 }  // namespace wh
 
-// One (mel tile MT, frame tile FT) unit of a whole, unmasked 48-frame tile of an NM-bin extractor.
+// One (mel tile MT, frame tile FT) unit of a whole 48-frame tile of an NM-bin extractor.
 //   a_lane : this lane's A-operand base (mel weights, LDS), b_lane : its B-operand row base of frame tile FT (panel)
 //   out_u  : scalar pointer out_clip + t0 + MT * 16 * n_frames + FT * 16;  o_r : per-lane store offsets, r = 0..3
-template <int NM, int MT>
+//   kMask  : the clip has SpecAugment masks -- tbits = the tile's time-mask bits of frame tile FT (16), mbits = the
+//            clip's mel-mask bits of mel tile MT (16), both wave-uniform: a unit no mask touches (most of them) takes
+//            the plain stores after one scalar test, the others write 0.0 over the masked cells
+template <int NM, int MT, bool kMask>
 __device__ __forceinline__ void mel_unit_static(const float* __restrict__ a_lane, const float* __restrict__ b_lane,
                                            float* __restrict__ out_u, const unsigned (&o_r)[4], float mel_floor,
-                                           float y_bias, float& run_max, float& tile_min) {
+                                           float y_bias, float& run_max, float& tile_min, unsigned tbits, unsigned mbits,
+                                           int lane) {
     using P = wh::StaticPlan<NM>;
     constexpr int KS = P::kstart[MT], NG = P::nsteps[MT] / 4, AO = P::aoff[MT];
     const f32x4* __restrict__ a = reinterpret_cast<const f32x4*>(a_lane + AO);
@@ -201,12 +205,22 @@ __device__ __forceinline__ void mel_unit_static(const float* __restrict__ a_lane
         acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc2, 0, 0, 0);
     }
     acc += acc2;
-    float mv[4];
+    float mv[4], yv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         mv[r] = fmaxf(acc[r], mel_floor);
-        out_u[o_r[r]] = fmaf(__log2f(mv[r]), 0.25f * 0.30102999566398120f, y_bias);
+        yv[r] = fmaf(__log2f(mv[r]), 0.25f * 0.30102999566398120f, y_bias);
     }
+    if (kMask && (tbits | mbits) != 0u) {                             // wave-uniform
+        const bool tmasked = (tbits >> (lane & 15)) & 1u;
+        const unsigned mb = (mbits >> ((lane >> 4) * 4)) & 15u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out_u[o_r[r]] = (tmasked || ((mb >> r) & 1u)) ? 0.0f : yv[r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out_u[o_r[r]] = yv[r];
+    }
+    // max / min count the masked cells too: the masks are applied to the finished features (src/data.py:185-194)
     run_max = fmaxf(fmaxf(run_max, fmaxf(mv[0], mv[1])), fmaxf(mv[2], mv[3]));
     tile_min = fminf(fminf(tile_min, fminf(mv[0], mv[1])), fminf(mv[2], mv[3]));
 }
@@ -560,16 +574,20 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         // operands -- across unit boundaries too -- are read while the current four steps multiply.
         // (Running a unit's epilogue under the first MFMAs of the next unit was measured slower: 1.15 vs 1.08 ms.)
         float tile_min = 3.0e38f;
-        if (static_plan != 0 && nm == 0 && t0 + kTileFrames <= min(n_frames, key_frames)) {
-            // whole, unmasked tile of an 80- or 128-bin extractor: the wave's units from the static plan (the same
-            // assignment as tables.cpp's: 48 / 44 / 44 / 44 k-steps per wave for 80 bins, 52 / 52 / 52 / 48 for 128)
+        if (static_plan != 0 && t0 + kTileFrames <= min(n_frames, key_frames)) {
+            // whole tile of an 80- or 128-bin extractor: the wave's units from the static plan (the same assignment
+            // as tables.cpp's: 48 / 44 / 44 / 44 k-steps per wave for 80 bins, 52 / 52 / 52 / 48 for 128)
             float* __restrict__ ob = out_clip + t0;
             const float* b0 = smem + brow0;
             const float* b1 = smem + brow1;
             const float* b2 = smem + brow2;
             const size_t nf16 = (size_t)16 * n_frames;
 #define STTFE_U(NM, MT, FT) \
-    mel_unit_static<NM, MT>(a_lane, b##FT, ob + MT * nf16 + FT * 16, o_r, mel_floor, y_bias, run_max, tile_min)
+    mel_unit_static<NM, MT, STTFE_MASKED>(a_lane, b##FT, ob + MT * nf16 + FT * 16, o_r, mel_floor, y_bias, run_max, tile_min, \
+                                          (unsigned)(tmask >> (FT * 16)) & 0xffffu,                                     \
+                                          (unsigned)((MT < 4 ? melmask_lo : melmask_hi) >> ((MT & 3) * 16)) & 0xffffu, lane)
+            if (nm == 0) {
+#define STTFE_MASKED false
             if (static_plan == 80) {
                 if (wave == 0) {
                     STTFE_U(80, 4, 0); STTFE_U(80, 3, 2); STTFE_U(80, 2, 2);
@@ -594,6 +612,36 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
                     STTFE_U(128, 5, 0); STTFE_U(128, 6, 0); STTFE_U(128, 6, 2);
                     STTFE_U(128, 0, 0); STTFE_U(128, 0, 1); STTFE_U(128, 0, 2);
                 }
+            }
+#undef STTFE_MASKED
+            } else {
+#define STTFE_MASKED true
+            if (static_plan == 80) {
+                if (wave == 0) {
+                    STTFE_U(80, 4, 0); STTFE_U(80, 3, 2); STTFE_U(80, 2, 2);
+                } else if (wave == 1) {
+                    STTFE_U(80, 4, 1); STTFE_U(80, 1, 0); STTFE_U(80, 1, 1); STTFE_U(80, 0, 0);
+                } else if (wave == 2) {
+                    STTFE_U(80, 4, 2); STTFE_U(80, 2, 0); STTFE_U(80, 2, 1); STTFE_U(80, 0, 1);
+                } else {
+                    STTFE_U(80, 3, 0); STTFE_U(80, 3, 1); STTFE_U(80, 1, 2); STTFE_U(80, 0, 2);
+                }
+            } else {
+                if (wave == 0) {
+                    STTFE_U(128, 7, 0); STTFE_U(128, 5, 1); STTFE_U(128, 4, 0);
+                    STTFE_U(128, 1, 0); STTFE_U(128, 1, 1); STTFE_U(128, 1, 2);
+                } else if (wave == 1) {
+                    STTFE_U(128, 7, 1); STTFE_U(128, 6, 1); STTFE_U(128, 4, 1);
+                    STTFE_U(128, 2, 0); STTFE_U(128, 2, 1); STTFE_U(128, 2, 2);
+                } else if (wave == 2) {
+                    STTFE_U(128, 7, 2); STTFE_U(128, 5, 2); STTFE_U(128, 4, 2);
+                    STTFE_U(128, 3, 0); STTFE_U(128, 3, 1); STTFE_U(128, 3, 2);
+                } else {
+                    STTFE_U(128, 5, 0); STTFE_U(128, 6, 0); STTFE_U(128, 6, 2);
+                    STTFE_U(128, 0, 0); STTFE_U(128, 0, 1); STTFE_U(128, 0, 2);
+                }
+            }
+#undef STTFE_MASKED
             }
 #undef STTFE_U
         } else {
