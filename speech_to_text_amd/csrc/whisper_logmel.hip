@@ -341,18 +341,43 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     float raw0[28], raw1[28];                      // the two passes of the NEXT tile, loaded a whole tile ahead
     bool raw_ready = false;                        // raw0 / raw1 already hold the first tile of the current item
 
-    // zero the slabs once (pad cells are read by zero-weight MFMA steps and must be finite), stage tables
-    for (int i = tid; i < kWinOff; i += kThreads) smem[i] = 0.f;
-    // window as [j][n1] and twiddles W400^(j k1) as [j][k1]: each lane reads its 20 values as b128 words
-    for (int i = tid; i < 400; i += kThreads) smem[kWinOff + (i % 20) * 20 + i / 20] = tab->window[i];
-    for (int i = tid; i < 800; i += kThreads) {
-        const int c = i >> 1, k1 = c / 20, jj = c - 20 * k1;
-        smem[kTwOff + jj * kTwStride + 2 * k1 + (i & 1)] = tab->twiddle[i];
-    }
+    // zero the slabs once (pad cells are read by zero-weight MFMA steps and must be finite), stage tables.
+    // Every global load of the staging is requested before the first LDS store: as copy loops (load, store, load, ...)
+    // the 18 + 4 + 2 dependent round trips per thread were ~15 us of every launch (a quarter of a 512-clip config-3 launch).
     {
-        const float* __restrict__ afrag_g = reinterpret_cast<const float*>(tab + 1);
-        const int na = min(tab->afrag_floats, kMaxAfragFloats);
-        for (int i = tid; i < na; i += kThreads) smem[kAfragOff + i] = afrag_g[i];
+        static_assert(sizeof(WhisperTablesHeader) % 16 == 0, "the mel weights behind the header are read as 16-byte words");
+        const f32x4* __restrict__ afrag4 = reinterpret_cast<const f32x4*>(tab + 1);
+        const int na4 = min(tab->afrag_floats, kMaxAfragFloats) >> 2;
+        constexpr int kA = (kMaxAfragFloats / 4 + kThreads - 1) / kThreads;
+        f32x4 av[kA];
+        float wv[2], tv[4];
+#pragma unroll
+        for (int k = 0; k < kA; ++k) {
+            const int i = tid + k * kThreads;
+            av[k] = afrag4[min(i, na4 - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) wv[k] = tab->window[min(tid + k * kThreads, 399)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tv[k] = tab->twiddle[min(tid + k * kThreads, 799)];
+        for (int i = tid; i < kWinOff; i += kThreads) smem[i] = 0.f;
+        // window as [j][n1] and twiddles W400^(j k1) as [j][k1]: each lane reads its 20 values as b128 words
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + k * kThreads;
+            if (i < 400) smem[kWinOff + (i % 20) * 20 + i / 20] = wv[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = tid + k * kThreads;
+            const int c = i >> 1, k1 = c / 20, jj = c - 20 * k1;
+            if (i < 800) smem[kTwOff + jj * kTwStride + 2 * k1 + (i & 1)] = tv[k];
+        }
+#pragma unroll
+        for (int k = 0; k < kA; ++k) {
+            const int i = tid + k * kThreads;
+            if (i < na4) reinterpret_cast<f32x4*>(smem + kAfragOff)[i] = av[k];
+        }
         int* desc = reinterpret_cast<int*>(smem + kDescOff);
         if (tid < kWaves * kMaxUnitsPerWave)
             reinterpret_cast<int4v*>(desc)[tid] = reinterpret_cast<const int4v*>(&tab->plan.desc[0][0][0])[tid];
