@@ -82,7 +82,9 @@ constexpr int kMaxAfragFloats = 4608;                 // 53 (80 mels) / 56 (128 
 constexpr int kDescOff = kAfragOff + kMaxAfragFloats;     // per wave: 8 x {kstart, nsteps, aoff, mt | ft << 8}, then the unit counts
 constexpr int kTicketOff = kDescOff + kWaves * kMaxUnitsPerWave * 4 + kWaves;    // 3 words: work-item hand-over slots
 constexpr int kMaskOff = kTicketOff + 4;              // the current clip's SpecAugment masks: STTFE_MAX_MASKS x {axis, start, end}
-constexpr int kLdsFloats = kMaskOff + 3 * STTFE_MAX_MASKS;   // ~65 KB -> 2 workgroups per CU
+constexpr int kPlanOff = kMaskOff + 3 * STTFE_MAX_MASKS;      // ragged batches: exclusive prefix of the clips' run counts
+constexpr int kMaxPlanClips = 3072;                   // (12 KB; larger batches keep the dense run x clip item space)
+constexpr int kLdsFloats = kPlanOff + kMaxPlanClips + 1;   // ~77 KB -> 2 workgroups per CU
 }  // namespace wh
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -242,6 +244,10 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef STTFE_STAMPS
+    unsigned long long stamp_entry;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_entry)::"memory");
+#endif
     const int p = lane / 20;                 // pair within the wave (3 = idle lanes 60..63)
     const int j = lane - p * 20;
     const bool active = lane < 60;
@@ -309,12 +315,70 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     }
     tiles_per_block = __builtin_amdgcn_readfirstlane(tiles_per_block);
     const int n_runs = (max_tiles + tiles_per_block - 1) / tiles_per_block;
-    const int n_items = n_runs * batch;
+    // Item space.  Dense: item = run * batch + clip for the runs the LONGEST clip reaches -- every item exists for
+    // uniform batches, but in a ragged batch half of them are empty, and an empty item still costs a ticket round trip
+    // and a barrier (11 % + 5 % of the kernel on config 4, tools/stamps.py).  Ragged batches of up to kMaxPlanClips
+    // clips are therefore compacted: every workgroup builds the exclusive prefix of the clips' own run counts in LDS
+    // (clip-major items, plan[batch] of them) and finds an item's clip by bisection.
+    auto runs_of = [&](int n_valid) {
+        return (min(n_tiles, first_pad_tile_of(n_valid)) + tiles_per_block - 1) / tiles_per_block;
+    };
+    int* plan = reinterpret_cast<int*>(smem + kPlanOff);
+    const bool planned = __builtin_amdgcn_readfirstlane(
+        (batch <= kMaxPlanClips && batch <= 16384 && runs_of(min_len) != n_runs) ? 1 : 0);
+    int n_items = n_runs * batch;
+    if (planned) {
+        constexpr int kPer = kMaxPlanClips / kThreads;              // consecutive clips per thread
+        const int per = (batch + kThreads - 1) / kThreads;
+        int before[kPer], sum = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int c = tid * per + k;
+            before[k] = sum;
+            if (k < per && c < batch) sum += runs_of(clamp_len(lengths[c]));
+        }
+        int incl = sum;                                                // inclusive scan over the wave, then over the waves
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) reinterpret_cast<int*>(smem)[wave] = incl;
+        __syncthreads();
+        int base = incl - sum;
+        for (int w = 0; w < wave; ++w) base += reinterpret_cast<const int*>(smem)[w];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int c = tid * per + k;
+            if (k < per && c < batch) plan[c] = base + before[k];
+        }
+        if (tid == kThreads - 1) plan[batch] = base + sum;
+        __syncthreads();
+        n_items = plan[batch];
+    }
+    // item -> (clip, run)
+    auto decode = [&](int it, int& clip_out, int& run_out) {
+        if (planned) {
+            int lo = 0, hi = batch;                                    // plan[lo] <= it < plan[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (plan[mid] <= it) lo = mid;
+                else hi = mid;
+            }
+            clip_out = __builtin_amdgcn_readfirstlane(lo);
+            run_out = __builtin_amdgcn_readfirstlane(it - plan[lo]);
+        } else {
+            run_out = __builtin_amdgcn_readfirstlane(it / batch);
+            clip_out = __builtin_amdgcn_readfirstlane(it - run_out * batch);
+        }
+    };
     int item = blockIdx.x, next_item = 0;
     if (item >= n_items) return;
+    int clip_cur, run_cur, clip_nx = 0, run_nx = 0;
+    decode(item, clip_cur, run_cur);
     // length / offset of the current item and of the next one (requested one item ahead)
-    int len_cur = lengths[item % batch];
-    int64_t off_cur = offsets[item % batch];
+    int len_cur = lengths[clip_cur];
+    int64_t off_cur = offsets[clip_cur];
     int len_next = 0;
     int64_t off_next = 0;
     unsigned iter = 0;
@@ -386,6 +450,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     }
     __syncthreads();
     next_item = (int)min(reinterpret_cast<const unsigned*>(smem + kTicketOff)[0], (unsigned)n_items);
+    if (next_item < n_items) decode(next_item, clip_nx, run_nx);
 
     const float* afrag = smem + kAfragOff;
     const int4v* desc = reinterpret_cast<const int4v*>(smem + kDescOff) + wave * kMaxUnitsPerWave;
@@ -494,12 +559,14 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 #pragma unroll
     for (int r = 0; r < 4; ++r) o_r[r] = (unsigned)(((lane >> 4) * 4 + r) * n_frames + (lane & 15));
 #ifdef STTFE_STAMPS
-    unsigned long long stamp_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+    // slots 0-9: phases of the tile loop; 10: kernel entry -> item loop; 11: item switches (end of an item's last tile
+    // -> start of the next item's first tile, empty items included); 12: after the last item; 13 / 14: entry / exit time
+    unsigned long long stamp_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = stamp_entry;
+    STAMP(10);
 #endif
 
     while (item < n_items) {
-      const int run = __builtin_amdgcn_readfirstlane(item / batch), clip = item - run * batch;
+      const int run = run_cur, clip = clip_cur;
       // (lengths / offsets are workgroup-uniform: move them to scalar registers once they have arrived)
       const int n_valid = clamp_len(__builtin_amdgcn_readfirstlane(len_cur));
       const int64_t off_x = ((int64_t)__builtin_amdgcn_readfirstlane((int)(off_cur >> 32)) << 32) |
@@ -516,8 +583,8 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
       }
       if (tid == 0 && next_item < n_items) my_ticket = atomicAdd(ticket, 1u);     // -> the item after the next
       if (next_item < n_items) {                   // lands while this item is processed
-          len_next = lengths[next_item % batch];
-          off_next = offsets[next_item % batch];
+          len_next = lengths[clip_nx];
+          off_next = offsets[clip_nx];
       }
       const int tile_begin = run * tiles_per_block;
       const int tile_end = min(min(tile_begin + tiles_per_block, n_tiles), first_pad_tile_of(n_valid));
@@ -540,6 +607,9 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
       float run_max = 0.0f;                         // mel energies (>= 1e-10 once any cell was produced)
       for (int tile = tile_begin; tile < tile_end; ++tile) {
         const int t0 = tile * kTileFrames;
+#ifdef STTFE_STAMPS
+        if (tile == tile_begin) STAMP(11);
+#endif
         {
             f2 ya[20], yb[20], pw0[11], pw1[11], q0[10], q1[10];
             f32x4 ra[10], rb[10];
@@ -571,7 +641,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         } else if (next_item < n_items) {
             // (the empty asm makes these values opaque here: otherwise the compiler computes the 56 load indices and
             // bounds predicates of the next item at the top of this item and spills them across the whole tile loop)
-            int nv = clamp_len(__builtin_amdgcn_readfirstlane(len_next)), tb = __builtin_amdgcn_readfirstlane((next_item / batch) * tiles_per_block);
+            int nv = clamp_len(__builtin_amdgcn_readfirstlane(len_next)), tb = __builtin_amdgcn_readfirstlane(run_nx * tiles_per_block);
             asm volatile("" : "+v"(nv), "+v"(tb));
             nv = __builtin_amdgcn_readfirstlane(nv);
             tb = __builtin_amdgcn_readfirstlane(tb);
@@ -770,14 +840,20 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
       const int after_next = (int)min(*slot, (unsigned)n_items);
       ++iter;
       item = next_item;
+      clip_cur = clip_nx;
+      run_cur = run_nx;
       next_item = after_next;
+      if (next_item < n_items) decode(next_item, clip_nx, run_nx);
       len_cur = len_next;
       off_cur = off_next;
     }
 #ifdef STTFE_STAMPS
     if (g_stamp_buf && lane == 0) {
-        unsigned long long* dst = g_stamp_buf + ((size_t)blockIdx.x * kWaves + wave) * 10;
-        for (int i = 0; i < 10; ++i) dst[i] = stamp_sum[i];
+        STAMP(12);
+        stamp_sum[13] = stamp_entry;
+        stamp_sum[14] = stamp_prev;
+        unsigned long long* dst = g_stamp_buf + ((size_t)blockIdx.x * kWaves + wave) * 16;
+        for (int i = 0; i < 16; ++i) dst[i] = stamp_sum[i];
     }
 #endif
 }
