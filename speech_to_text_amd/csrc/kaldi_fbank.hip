@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     unsigned iter = 0;
     while (item < n_items) {
     unsigned my_ticket = 0;
-    if (tid == 0) my_ticket = atomicAdd(ticket, 1u);               // the workgroup's next item, needed at the end of this one
+    if (tid == 0) my_ticket = atomicInc(ticket, 0xffffffffu);               // the workgroup's next item, needed at the end of this one
     const int clip = __builtin_amdgcn_readfirstlane(item / n_runs), run = item - clip * n_runs;
     n_valid = __builtin_amdgcn_readfirstlane(lengths[clip]);
     {
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(kaldi64::kThreads, kaldi64::kWgPerCu) void kaldi_fb
     unsigned iter = 0;
     while (item < n_items) {
         unsigned my_ticket = 0;
-        if (tid == 0) my_ticket = atomicAdd(ticket, 1u);           // the workgroup's next item, needed at the end of this one
+        if (tid == 0) my_ticket = atomicInc(ticket, 0xffffffffu);           // the workgroup's next item, needed at the end of this one
         const int clip = __builtin_amdgcn_readfirstlane(item / n_runs), run = item - clip * n_runs;
         const int n_valid = __builtin_amdgcn_readfirstlane(lengths[clip]);
         const float* __restrict__ x;

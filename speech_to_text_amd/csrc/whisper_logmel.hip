@@ -268,8 +268,13 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         return mode == kModeTorchVarlen ? (1 + n_valid / kHop + kTileFrames - 1) / kTileFrames
                                         : (n_valid + kNfft / 2 + kHop * kTileFrames - 1) / (kHop * kTileFrames);
     };
+    // (atomicInc with an all-ones bound = "add 1, return the old value".  With atomicAdd the compiler's atomic optimiser
+    // turns the one-lane add into a wave reduction whose result it broadcasts with v_readfirstlane RIGHT AFTER the
+    // atomic: s_waitcnt vmcnt(0) at the top of every item, i.e. a full device-atomic round trip -- and every store and
+    // prefetch in flight -- before wave 0 could go on.  The optimiser leaves inc alone.  Measured: -2.5 % on the float32
+    // Kaldi kernel, whose items are short; neutral here, where the other resident workgroup covers wave 0's wait.)
     unsigned my_ticket = 0;
-    if (tid == 0) my_ticket = atomicAdd(ticket, 1u);               // -> the workgroup's second item
+    if (tid == 0) my_ticket = atomicInc(ticket, 0xffffffffu);               // -> the workgroup's second item
     // longest and shortest clip of the batch (every workgroup computes the same values; skipped for very large batches)
     int max_len = kMaxSamples, min_len = 0, sum_tiles = 0;             // sum_tiles: computed tiles of the whole batch
     if (batch <= 16384) {
@@ -581,7 +586,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
           mel_floor = 1e-10f / (sc * sc);
           y_bias = 1.0f + 0.5f * 0.30102999566398120f * __log2f(sc);
       }
-      if (tid == 0 && next_item < n_items) my_ticket = atomicAdd(ticket, 1u);     // -> the item after the next
+      if (tid == 0 && next_item < n_items) my_ticket = atomicInc(ticket, 0xffffffffu);     // -> the item after the next
       if (next_item < n_items) {                   // lands while this item is processed
           len_next = lengths[clip_nx];
           off_next = offsets[clip_nx];
@@ -594,7 +599,8 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
       float* __restrict__ out_clip = out + (size_t)clip * n_mels * n_frames;
       // SpecAugment: mel-axis masks as two 64-bit words for the clip; time-axis masks per tile
       // The clip's mask table goes to LDS once per item (read per tile from global memory it cost one HBM round
-      // trip per tile); it is first read after the "panel complete" barrier of the item's first tile.
+      // trip per tile); it is first read after the "panel complete" barrier of the item's first tile.  (Wave 0 waits
+      // for this load at the top of every item; requesting it an item ahead was measured neutral.)
       const int nm = mask_tbl ? n_masks : 0;
       int32_t* clip_masks = reinterpret_cast<int32_t*>(smem + kMaskOff);
       if (tid < 3 * nm) clip_masks[tid] = mask_tbl[(size_t)clip * n_masks * 3 + tid];
@@ -838,12 +844,18 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
       if (tid == 0) *slot = (next_item < n_items) ? my_ticket + gridDim.x : (unsigned)n_items;
       __syncthreads();
       const int after_next = (int)min(*slot, (unsigned)n_items);
+#ifdef STTFE_STAMPS
+      STAMP(1);       // diagnostic: end of the item's last tile -> ticket hand-over barrier passed
+#endif
       ++iter;
       item = next_item;
       clip_cur = clip_nx;
       run_cur = run_nx;
       next_item = after_next;
       if (next_item < n_items) decode(next_item, clip_nx, run_nx);
+#ifdef STTFE_STAMPS
+      STAMP(9);       // diagnostic: item decode
+#endif
       len_cur = len_next;
       off_cur = off_next;
     }
