@@ -255,7 +255,8 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 
     // Work items are (tile run, clip) pairs, run-major: item = run * batch + clip, for the runs that the longest clip
     // of the batch reaches.  A workgroup stages the tables once and then takes items from a ticket counter in the
-    // workspace (zeroed by the host): the first item is blockIdx.x, every further one gridDim.x + atomicAdd(ticket).
+    // workspace (zeroed by the host): the first items are blockIdx.x and gridDim.x + blockIdx.x, every further one
+    // 2 gridDim.x + atomicInc(ticket).
     // Thread 0 requests the ticket two items ahead and publishes it through LDS at the end of an item, so that the
     // atomic, the length / offset of the next item and its first PCM tile are all in flight under useful work.
     // Every workgroup leaves its loop after at most n_items tickets; all threads of a workgroup take the same path.
@@ -273,17 +274,55 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     // atomic: s_waitcnt vmcnt(0) at the top of every item, i.e. a full device-atomic round trip -- and every store and
     // prefetch in flight -- before wave 0 could go on.  The optimiser leaves inc alone.  Measured: -2.5 % on the float32
     // Kaldi kernel, whose items are short; neutral here, where the other resident workgroup covers wave 0's wait.)
+    // The first TWO items of a workgroup are static (blockIdx.x and gridDim.x + blockIdx.x); tickets start at the third.
+    // With a ticket for the second item every workgroup's first act was an atomic on the same word, needed before its
+    // first tile: 512 serialised device-scope atomics, i.e. ~10 us before the last workgroup could start (12 us of
+    // "start-up" per workgroup in tools/stamps.py).
     unsigned my_ticket = 0;
-    if (tid == 0) my_ticket = atomicInc(ticket, 0xffffffffu);               // -> the workgroup's second item
+    // (requested first of all: the table loads are in flight under the reduction of the clip lengths below)
+    static_assert(sizeof(WhisperTablesHeader) % 16 == 0, "the mel weights behind the header are read as 16-byte words");
+    constexpr int kA = (kMaxAfragFloats / 4 + kThreads - 1) / kThreads;
+    f32x4 av[kA];
+    float wv[2], tv[4];
+    const int na4 = min(tab->afrag_floats, kMaxAfragFloats) >> 2;
+    {
+        const f32x4* __restrict__ afrag4 = reinterpret_cast<const f32x4*>(tab + 1);
+#pragma unroll
+        for (int k = 0; k < kA; ++k) av[k] = afrag4[min(tid + k * kThreads, na4 - 1)];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) wv[k] = tab->window[min(tid + k * kThreads, 399)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tv[k] = tab->twiddle[min(tid + k * kThreads, 799)];
+    }
     // longest and shortest clip of the batch (every workgroup computes the same values; skipped for very large batches)
     int max_len = kMaxSamples, min_len = 0, sum_tiles = 0;             // sum_tiles: computed tiles of the whole batch
+    // this thread's clips tid * per + k (batches of up to kMaxPlanClips): all lengths requested at once and kept for the
+    // item plan below -- as a load-use loop every trip was a round trip of its own
+    constexpr int kPer = kMaxPlanClips / kThreads;
+    const int per = (batch + kThreads - 1) / kThreads;
+    int lens[kPer];
+    if (batch <= kMaxPlanClips) {
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) lens[k] = clamp_len(lengths[min(tid * per + k, batch - 1)]);
+    }
     if (batch <= 16384) {
         int m = 0, mn = kMaxSamples, st = 0;
-        for (int i = tid; i < batch; i += kThreads) {
-            const int l = clamp_len(lengths[i]);
-            m = max(m, l);
-            mn = min(mn, l);
-            st += min(n_tiles, first_pad_tile_of(l));
+        if (batch <= kMaxPlanClips) {
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) {
+                if (k < per && tid * per + k < batch) {
+                    m = max(m, lens[k]);
+                    mn = min(mn, lens[k]);
+                    st += min(n_tiles, first_pad_tile_of(lens[k]));
+                }
+            }
+        } else {
+            for (int i = tid; i < batch; i += kThreads) {
+                const int l = clamp_len(lengths[i]);
+                m = max(m, l);
+                mn = min(mn, l);
+                st += min(n_tiles, first_pad_tile_of(l));
+            }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -333,14 +372,12 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         (batch <= kMaxPlanClips && batch <= 16384 && runs_of(min_len) != n_runs) ? 1 : 0);
     int n_items = n_runs * batch;
     if (planned) {
-        constexpr int kPer = kMaxPlanClips / kThreads;              // consecutive clips per thread
-        const int per = (batch + kThreads - 1) / kThreads;
         int before[kPer], sum = 0;
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
             const int c = tid * per + k;
             before[k] = sum;
-            if (k < per && c < batch) sum += runs_of(clamp_len(lengths[c]));
+            if (k < per && c < batch) sum += runs_of(lens[k]);
         }
         int incl = sum;                                                // inclusive scan over the wave, then over the waves
 #pragma unroll
@@ -364,14 +401,18 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     // item -> (clip, run)
     auto decode = [&](int it, int& clip_out, int& run_out) {
         if (planned) {
-            int lo = 0, hi = batch;                                    // plan[lo] <= it < plan[hi]
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (plan[mid] <= it) lo = mid;
-                else hi = mid;
-            }
-            clip_out = __builtin_amdgcn_readfirstlane(lo);
-            run_out = __builtin_amdgcn_readfirstlane(it - plan[lo]);
+            // largest c with plan[c] <= it (plan is strictly increasing: every clip has a run), two 64-way steps: the
+            // lanes sample plan at 64 points / read one block of it, and a ballot counts the entries <= it
+            // (a bisection's 12 dependent LDS reads were 1.7 k cycles per item)
+            const int stride = (batch + 63) >> 6;
+            const int c1 = lane * stride;
+            const bool le1 = c1 < batch && plan[min(c1, batch)] <= it;
+            const int block = __popcll(__ballot(le1)) - 1;                  // >= 0: plan[0] = 0 <= it
+            const int c2 = block * stride + lane;
+            const bool le2 = lane < stride && c2 < batch && plan[min(c2, batch)] <= it;
+            const int c = block * stride + __popcll(__ballot(le2)) - 1;
+            clip_out = __builtin_amdgcn_readfirstlane(c);
+            run_out = __builtin_amdgcn_readfirstlane(it - plan[c]);
         } else {
             run_out = __builtin_amdgcn_readfirstlane(it / batch);
             clip_out = __builtin_amdgcn_readfirstlane(it - run_out * batch);
@@ -414,21 +455,6 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     // Every global load of the staging is requested before the first LDS store: as copy loops (load, store, load, ...)
     // the 18 + 4 + 2 dependent round trips per thread were ~15 us of every launch (a quarter of a 512-clip config-3 launch).
     {
-        static_assert(sizeof(WhisperTablesHeader) % 16 == 0, "the mel weights behind the header are read as 16-byte words");
-        const f32x4* __restrict__ afrag4 = reinterpret_cast<const f32x4*>(tab + 1);
-        const int na4 = min(tab->afrag_floats, kMaxAfragFloats) >> 2;
-        constexpr int kA = (kMaxAfragFloats / 4 + kThreads - 1) / kThreads;
-        f32x4 av[kA];
-        float wv[2], tv[4];
-#pragma unroll
-        for (int k = 0; k < kA; ++k) {
-            const int i = tid + k * kThreads;
-            av[k] = afrag4[min(i, na4 - 1)];
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) wv[k] = tab->window[min(tid + k * kThreads, 399)];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) tv[k] = tab->twiddle[min(tid + k * kThreads, 799)];
         for (int i = tid; i < kWinOff; i += kThreads) smem[i] = 0.f;
         // window as [j][n1] and twiddles W400^(j k1) as [j][k1]: each lane reads its 20 values as b128 words
 #pragma unroll
@@ -451,7 +477,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         if (tid < kWaves * kMaxUnitsPerWave)
             reinterpret_cast<int4v*>(desc)[tid] = reinterpret_cast<const int4v*>(&tab->plan.desc[0][0][0])[tid];
         if (tid < kWaves) desc[4 * kWaves * kMaxUnitsPerWave + tid] = tab->plan.wave_nunits[tid];
-        if (tid == 0) reinterpret_cast<unsigned*>(smem + kTicketOff)[0] = my_ticket + gridDim.x;
+        if (tid == 0) reinterpret_cast<unsigned*>(smem + kTicketOff)[0] = blockIdx.x + gridDim.x;
     }
     __syncthreads();
     next_item = (int)min(reinterpret_cast<const unsigned*>(smem + kTicketOff)[0], (unsigned)n_items);
@@ -841,7 +867,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
       // publish the ticket taken at the top of this item (two alternating LDS slots: a slot is rewritten only after
       // the barrier of the following item, which every thread reaches after this read)
       unsigned* slot = reinterpret_cast<unsigned*>(smem + kTicketOff) + 1 + (iter & 1u);
-      if (tid == 0) *slot = (next_item < n_items) ? my_ticket + gridDim.x : (unsigned)n_items;
+      if (tid == 0) *slot = (next_item < n_items) ? my_ticket + 2 * gridDim.x : (unsigned)n_items;
       __syncthreads();
       const int after_next = (int)min(*slot, (unsigned)n_items);
 #ifdef STTFE_STAMPS
