@@ -9,7 +9,7 @@ from speech_to_text_amd.synth import synth_batch_device
 import numpy as np
 from speech_to_text_amd.synth import common_voice_lengths
 WL = os.environ.get("STAMP_WL", "full")          # full: 256 x 30 s clips; cv: 1024 Common-Voice-length clips
-B = 256 if WL == "full" else 1024
+B = int(os.environ.get("STAMP_B", "256" if WL == "full" else "1024"))
 N_MELS = int(os.environ.get("STAMP_MELS", "80"))
 dev = torch.device("cuda:0")
 L = _lib.lib()
