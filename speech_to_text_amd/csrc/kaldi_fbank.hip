@@ -79,6 +79,77 @@ __device__ __forceinline__ int kaldi_num_frames(int n, int max_frames, int t_max
     return t > t_max ? t_max : t;
 }
 
+// ---- work items of the two persistent Kaldi kernels ----
+// Dense items are (clip, run of tiles_per_block 32-frame tiles) for the runs the LONGEST clip reaches; on a ragged
+// batch (config 2: 2-10 s clips) 40 % of them are empty, and an empty item still costs a ticket round trip and a
+// barrier.  Batches of up to kKaldiPlanClips clips are compacted instead: every workgroup builds the exclusive prefix of
+// the clips' own run counts in LDS and finds an item's clip with two 64-way ballot steps (as the Whisper kernel does).
+constexpr int kKaldiPlanClips = 1024;
+struct KaldiItems {
+    const int* plan;        // LDS: plan[c] = items before clip c, plan[batch] = all items (compacted mode)
+    int n_items, n_runs, batch;
+    bool planned;
+};
+// Called by all 256 threads of the workgroup (contains barriers).  `plan` has kKaldiPlanClips + 1 ints, `scratch` 4.
+__device__ __forceinline__ KaldiItems kaldi_build_items(int* plan, int* scratch, const int32_t* __restrict__ lengths,
+                                                       int batch, int t_max, int max_frames, int tiles_per_block,
+                                                       int n_runs_dense, int n_items_dense) {
+    KaldiItems it{plan, n_items_dense, n_runs_dense, batch, batch <= kKaldiPlanClips};
+    if (!it.planned) return it;
+    constexpr int kPer = kKaldiPlanClips / kaldi::kThreads;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (batch + kaldi::kThreads - 1) / kaldi::kThreads;
+    int lens[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) lens[k] = lengths[min(tid * per + k, batch - 1)];      // all requested at once
+    int before[kPer], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        before[k] = sum;
+        if (k < per && tid * per + k < batch) {
+            const int T = kaldi_num_frames(lens[k], max_frames, t_max);
+            const int tiles = (T + kaldi::kTileFrames - 1) / kaldi::kTileFrames;
+            sum += (tiles + tiles_per_block - 1) / tiles_per_block;                        // 0 for a clip without a frame
+        }
+    }
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int w = 0; w < wave; ++w) base += scratch[w];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k)
+        if (k < per && tid * per + k < batch) plan[tid * per + k] = base + before[k];
+    if (tid == kaldi::kThreads - 1) plan[batch] = base + sum;
+    __syncthreads();
+    it.n_items = plan[batch];
+    return it;
+}
+// item -> (clip, run); all 64 lanes of the wave take part
+__device__ __forceinline__ void kaldi_decode_item(const KaldiItems& it, int item, int& clip, int& run) {
+    if (it.planned) {
+        // largest c with plan[c] <= item (clips without a frame have no items and lose the tie to their successor)
+        const int lane = threadIdx.x & 63;
+        const int stride = (it.batch + 63) >> 6;
+        const int c1 = lane * stride;
+        const bool le1 = c1 < it.batch && it.plan[min(c1, it.batch)] <= item;
+        const int block = __popcll(__ballot(le1)) - 1;
+        const int c2 = block * stride + lane;
+        const bool le2 = lane < stride && c2 < it.batch && it.plan[min(c2, it.batch)] <= item;
+        const int c = block * stride + __popcll(__ballot(le2)) - 1;
+        clip = __builtin_amdgcn_readfirstlane(c);
+        run = __builtin_amdgcn_readfirstlane(item - it.plan[c]);
+    } else {
+        clip = __builtin_amdgcn_readfirstlane(item / it.n_runs);
+        run = __builtin_amdgcn_readfirstlane(item - clip * it.n_runs);
+    }
+}
+
 // Persistent 256-thread workgroups (4 waves, <= 256 VGPRs, 74 KB LDS -> two per CU, grid = 2 x CUs).  A workgroup
 // stages window, twiddles and the per-wave unit plan in LDS once and then takes work items -- (clip, run of
 // consecutive 32-frame tiles), clip-major -- from a ticket counter in the workspace: ragged batches (config 2:
@@ -92,17 +163,20 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     const float* __restrict__ pcm, const int64_t* __restrict__ offsets,
     const int32_t* __restrict__ lengths, int n_mels, int t_max, int max_frames,
     const KaldiTablesHeader* __restrict__ tab, float* __restrict__ out, double* __restrict__ stats,
-    int tiles_per_block, int n_runs, int n_items, unsigned* __restrict__ ticket) {
+    int tiles_per_block, int n_runs, int n_items, unsigned* __restrict__ ticket, int batch) {
     using namespace kaldi;
     __shared__ __attribute__((aligned(16))) float smem[kLdsFloats];
     __shared__ unsigned s_next[2];
+    __shared__ int s_plan[kKaldiPlanClips + 1], s_scan[4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tab->magic != kKaldiMagic || tab->n_mels != n_mels) return;      // the CMVN pass poisons the output
+    const KaldiItems items = kaldi_build_items(s_plan, s_scan, lengths, batch, t_max, max_frames, tiles_per_block, n_runs, n_items);
+    n_items = items.n_items;
     int item = blockIdx.x;
     if (item >= n_items) return;
-    if (tab->magic != kKaldiMagic || tab->n_mels != n_mels) return;      // the CMVN pass poisons the output
     // per-item state (set at the top of the item loop; the lambdas below read it by reference)
     const float* __restrict__ x = pcm;
     int n_valid = 0;
@@ -177,17 +251,25 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     };
     const int prow0 = p_row(0), prow1 = p_row(1);
 
-    unsigned iter = 0;
+    // The first two items of a workgroup are static (blockIdx.x, gridDim.x + blockIdx.x), tickets start at the third;
+    // the ticket, clip, length and offset of the NEXT item are requested at the top of the current one.
+    unsigned iter = 0, my_ticket = 0;
+    int next_item = min((int)(blockIdx.x + gridDim.x), n_items);
+    int clip_cur, run_cur, clip_nx = 0, run_nx = 0;
+    kaldi_decode_item(items, item, clip_cur, run_cur);
+    if (next_item < n_items) kaldi_decode_item(items, next_item, clip_nx, run_nx);
+    int len_cur = lengths[clip_cur], len_nx = 0;
+    int64_t off_cur = offsets[clip_cur], off_nx = 0;
     while (item < n_items) {
-    unsigned my_ticket = 0;
-    if (tid == 0) my_ticket = atomicInc(ticket, 0xffffffffu);               // the workgroup's next item, needed at the end of this one
-    const int clip = __builtin_amdgcn_readfirstlane(item / n_runs), run = item - clip * n_runs;
-    n_valid = __builtin_amdgcn_readfirstlane(lengths[clip]);
-    {
-        const int64_t o = offsets[clip];
-        x = pcm + (((int64_t)__builtin_amdgcn_readfirstlane((int)(o >> 32)) << 32) |
-                   (uint32_t)__builtin_amdgcn_readfirstlane((int)o));
+    if (tid == 0 && next_item < n_items) my_ticket = atomicInc(ticket, 0xffffffffu);   // -> the item after the next
+    if (next_item < n_items) {
+        len_nx = lengths[clip_nx];
+        off_nx = offsets[clip_nx];
     }
+    const int clip = clip_cur, run = run_cur;
+    n_valid = __builtin_amdgcn_readfirstlane(len_cur);
+    x = pcm + (((int64_t)__builtin_amdgcn_readfirstlane((int)(off_cur >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)off_cur));
     const int T = kaldi_num_frames(n_valid, max_frames, t_max);
     const int n_tiles = (T + kTileFrames - 1) / kTileFrames;
     const int tile_begin = run * tiles_per_block;
@@ -374,10 +456,17 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
     }   // item has tiles
     // hand-over of the next item through one of two alternating LDS slots (a slot is rewritten only after the
     // barrier of the following item, which every thread reaches after this read)
-    if (tid == 0) s_next[iter & 1u] = my_ticket + gridDim.x;
+    if (tid == 0) s_next[iter & 1u] = next_item < n_items ? my_ticket + 2 * gridDim.x : (unsigned)n_items;
     __syncthreads();
-    item = (int)min(s_next[iter & 1u], (unsigned)n_items);
+    const int after_next = (int)min(s_next[iter & 1u], (unsigned)n_items);
     ++iter;
+    item = next_item;
+    clip_cur = clip_nx;
+    run_cur = run_nx;
+    len_cur = len_nx;
+    off_cur = off_nx;
+    next_item = after_next;
+    if (next_item < n_items) kaldi_decode_item(items, next_item, clip_nx, run_nx);
     }   // items
 }
 
@@ -495,17 +584,20 @@ __global__ __launch_bounds__(kaldi64::kThreads, kaldi64::kWgPerCu) void kaldi_fb
     const float* __restrict__ pcm, const int64_t* __restrict__ offsets,
     const int32_t* __restrict__ lengths, int n_mels, int t_max, int max_frames,
     const KaldiTablesHeader* __restrict__ tab, float* __restrict__ out,
-    int tiles_per_block, int n_runs, int n_items, unsigned* __restrict__ ticket) {
+    int tiles_per_block, int n_runs, int n_items, unsigned* __restrict__ ticket, int batch) {
     using namespace kaldi64;
     __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsBytes];
     __shared__ unsigned s_next[2];
+    __shared__ int s_plan[kKaldiPlanClips + 1], s_scan[4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tab->magic != kKaldiMagic || tab->n_mels != n_mels) return;      // the CMVN pass poisons the output
+    const KaldiItems items = kaldi_build_items(s_plan, s_scan, lengths, batch, t_max, max_frames, tiles_per_block, n_runs, n_items);
+    n_items = items.n_items;
     int item = blockIdx.x;
     if (item >= n_items) return;
-    if (tab->magic != kKaldiMagic || tab->n_mels != n_mels) return;      // the CMVN pass poisons the output
 
     // float64 section of the tables blob: window[400], W512 (cos, -sin)[512], then the mel bands and their weights
     const double* __restrict__ t64 = reinterpret_cast<const double*>(
@@ -541,18 +633,25 @@ __global__ __launch_bounds__(kaldi64::kThreads, kaldi64::kWgPerCu) void kaldi_fb
     const double2k* ltab = reinterpret_cast<const double2k*>(smem + kLogOff);
     const int mel_rounds = (2 * n_mels + 63) >> 6;
 
-    unsigned iter = 0;
+    // items: as in kaldi_fbank_kernel (two static items, then tickets; the next item's clip, length and offset are
+    // requested at the top of the current item)
+    unsigned iter = 0, my_ticket = 0;
+    int next_item = min((int)(blockIdx.x + gridDim.x), n_items);
+    int clip_cur, run_cur, clip_nx = 0, run_nx = 0;
+    kaldi_decode_item(items, item, clip_cur, run_cur);
+    if (next_item < n_items) kaldi_decode_item(items, next_item, clip_nx, run_nx);
+    int len_cur = lengths[clip_cur], len_nx = 0;
+    int64_t off_cur = offsets[clip_cur], off_nx = 0;
     while (item < n_items) {
-        unsigned my_ticket = 0;
-        if (tid == 0) my_ticket = atomicInc(ticket, 0xffffffffu);           // the workgroup's next item, needed at the end of this one
-        const int clip = __builtin_amdgcn_readfirstlane(item / n_runs), run = item - clip * n_runs;
-        const int n_valid = __builtin_amdgcn_readfirstlane(lengths[clip]);
-        const float* __restrict__ x;
-        {
-            const int64_t o = offsets[clip];
-            x = pcm + (((int64_t)__builtin_amdgcn_readfirstlane((int)(o >> 32)) << 32) |
-                       (uint32_t)__builtin_amdgcn_readfirstlane((int)o));
+        if (tid == 0 && next_item < n_items) my_ticket = atomicInc(ticket, 0xffffffffu);   // -> the item after the next
+        if (next_item < n_items) {
+            len_nx = lengths[clip_nx];
+            off_nx = offsets[clip_nx];
         }
+        const int clip = clip_cur, run = run_cur;
+        const int n_valid = __builtin_amdgcn_readfirstlane(len_cur);
+        const float* __restrict__ x = pcm + (((int64_t)__builtin_amdgcn_readfirstlane((int)(off_cur >> 32)) << 32) |
+                                             (uint32_t)__builtin_amdgcn_readfirstlane((int)off_cur));
         const int T = kaldi_num_frames(n_valid, max_frames, t_max);
         // this wave's frames of the run: 8 per tile
         const int f_first = run * tiles_per_block * kTileFrames + wave * kFramesPerWave;
@@ -740,10 +839,17 @@ __global__ __launch_bounds__(kaldi64::kThreads, kaldi64::kWgPerCu) void kaldi_fb
         }
         // hand-over of the next item through one of two alternating LDS slots (a slot is rewritten only after the
         // barrier of the following item, which every thread reaches after this read)
-        if (tid == 0) s_next[iter & 1u] = my_ticket + gridDim.x;
+        if (tid == 0) s_next[iter & 1u] = next_item < n_items ? my_ticket + 2 * gridDim.x : (unsigned)n_items;
         __syncthreads();
-        item = (int)min(s_next[iter & 1u], (unsigned)n_items);
+        const int after_next = (int)min(s_next[iter & 1u], (unsigned)n_items);
         ++iter;
+        item = next_item;
+        clip_cur = clip_nx;
+        run_cur = run_nx;
+        len_cur = len_nx;
+        off_cur = off_nx;
+        next_item = after_next;
+        if (next_item < n_items) kaldi_decode_item(items, next_item, clip_nx, run_nx);
     }
 }
 
@@ -1045,8 +1151,13 @@ extern "C" int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, 
     }();
     int tiles_per_block = tpb_env;
     if (tiles_per_block == 0) {
-        const long est = (long)batch * n_tiles / 2 / (8L * resident);
-        tiles_per_block = est < 2 ? 2 : (est > 8 ? 8 : (int)est);
+        // the float64 kernel is wave-local (no barrier per tile) and runs three workgroups per CU: single-tile items
+        // balance config 2 best there (1: 0.173, 2: 0.183, 3: 0.182, 4: 0.199 ms; float32 kernel 0.110 / 0.106 / 0.112 / 0.116)
+        const bool f64 = flags & STTFE_KALDI_F64;
+        const long wgs = f64 ? (long)kaldi64::kWgPerCu * current_device_cus() : resident;
+        const long est = (long)batch * n_tiles / 2 / (8L * wgs);
+        const long lo = f64 ? 1 : 2;
+        tiles_per_block = est < lo ? (int)lo : (est > 8 ? 8 : (int)est);
     }
     const int n_runs = (n_tiles + tiles_per_block - 1) / tiles_per_block;
     if ((long)n_runs * batch > 0x3fffffffL) return STTFE_E_UNSUPPORTED;
@@ -1059,10 +1170,10 @@ extern "C" int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, 
             const int res64 = kaldi64::kWgPerCu * current_device_cus();
             const int grid64 = n_items < res64 ? n_items : res64;
             hipLaunchKernelGGL(kaldi_fbank64_kernel, dim3(grid64), dim3(kaldi64::kThreads), 0, stream, pcm, offsets,
-                               lengths, n_mels, t_max, max_frames, tab, out, tiles_per_block, n_runs, n_items, ticket);
+                               lengths, n_mels, t_max, max_frames, tab, out, tiles_per_block, n_runs, n_items, ticket, batch);
         } else {
             hipLaunchKernelGGL(kaldi_fbank_kernel, dim3(grid), dim3(kaldi::kThreads), 0, stream, pcm, offsets,
-                               lengths, n_mels, t_max, max_frames, tab, out, stats, tiles_per_block, n_runs, n_items, ticket);
+                               lengths, n_mels, t_max, max_frames, tab, out, stats, tiles_per_block, n_runs, n_items, ticket, batch);
         }
     }
     {
