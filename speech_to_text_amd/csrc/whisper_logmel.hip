@@ -227,6 +227,18 @@ __device__ __forceinline__ void mel_unit_static(const float* __restrict__ a_lane
     tile_min = fminf(fminf(tile_min, fminf(mv[0], mv[1])), fminf(mv[2], mv[3]));
 }
 
+// First frame (a multiple of 4) from which every cell of a clip is the padding constant.  Zero padding to 30 s: frame t
+// reads samples [160 t - 200, 160 t + 200), so frames from ceil((n + 200) / 160) on see only zeros (clips within a
+// second of 30 s are left to the tile rule: the reflection at the 30 s end reads backwards).  Kernel 1 still computes
+// the cells of such frames inside its last tile (they come out as exactly the constant), but keeps them out of the
+// tile's minimum -- otherwise the last tile of EVERY short clip is flagged for kernel 2's clamp -- and kernel 2 fills
+// from here.  Variable-length mode keeps the tile rule (its padding is padding_value, written by kernel 1 up to the tile end).
+__device__ __forceinline__ int whisper_const_frame(int n_valid, int n_frames, int tile_pad_frame, int mode) {
+    if (mode == wh::kModeTorchVarlen || n_valid > wh::kMaxSamples - 16000) return tile_pad_frame;
+    const int f = ((n_valid + wh::kNfft / 2 + wh::kHop - 1) / wh::kHop + 3) & ~3;
+    return min(min(f, tile_pad_frame), n_frames);
+}
+
 #ifndef STTFE_WH_WAVES_PER_SIMD
 #define STTFE_WH_WAVES_PER_SIMD 2
 #endif
@@ -621,6 +633,8 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
       const int tile_end = min(min(tile_begin + tiles_per_block, n_tiles), first_pad_tile_of(n_valid));
       // frames that count for the per-clip maximum (and hold data rather than padding_value)
       const int key_frames = mode == kModeTorchVarlen ? 1 + n_valid / kHop : (mode == kModeTorchPadded ? n_frames + 1 : n_frames);
+      // frames from here on are the padding constant (kernel 2 fills them): not part of a tile's minimum
+      const int const_frame = whisper_const_frame(n_valid, n_frames, min(n_frames, min(n_tiles, first_pad_tile_of(n_valid)) * kTileFrames), mode);
       if (tile_begin < tile_end) {
       float* __restrict__ out_clip = out + (size_t)clip * n_mels * n_frames;
       // SpecAugment: mel-axis masks as two 64-bit words for the clip; time-axis masks per tile
@@ -701,7 +715,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         // operands -- across unit boundaries too -- are read while the current four steps multiply.
         // (Running a unit's epilogue under the first MFMAs of the next unit was measured slower: 1.15 vs 1.08 ms.)
         float tile_min = 3.0e38f;
-        if (static_plan != 0 && t0 + kTileFrames <= min(n_frames, key_frames)) {
+        if (static_plan != 0 && t0 + kTileFrames <= min(min(n_frames, key_frames), const_frame)) {
             // whole tile of an 80- or 128-bin extractor: the wave's units from the static plan (the same assignment
             // as tables.cpp's: 48 / 44 / 44 / 44 k-steps per wave for 80 bins, 52 / 52 / 52 / 48 for 128)
             float* __restrict__ ob = out_clip + t0;
@@ -823,7 +837,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
                 mv[r] = fmaxf(acc[r], mel_floor);
                 yv[r] = fmaf(__log2f(mv[r]), 0.25f * 0.30102999566398120f, y_bias);
             }
-            const bool whole = (mt * 16 + 16 <= n_mels) && (t0 + ft * 16 + 16 <= min(n_frames, key_frames));    // wave-uniform
+            const bool whole = (mt * 16 + 16 <= n_mels) && (t0 + ft * 16 + 16 <= min(min(n_frames, key_frames), const_frame));    // wave-uniform
             if (whole && nm == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -834,13 +848,13 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
             } else {
                 const bool tmasked = (tmask >> fl) & 1ull;
                 const unsigned mbits = (unsigned)((mel0 < 64 ? melmask_lo >> mel0 : melmask_hi >> (mel0 - 64)) & 15ull);
-                const bool counted = t0 + fl < key_frames, stored = t0 + fl < n_frames;
+                const bool counted = t0 + fl < key_frames, stored = t0 + fl < n_frames, varies = t0 + fl < const_frame;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (mel0 + r < n_mels) {
                         if (counted) {
                             run_max = fmaxf(run_max, mv[r]);
-                            tile_min = fminf(tile_min, mv[r]);
+                            if (varies) tile_min = fminf(tile_min, mv[r]);
                         }
                         if (stored)
                             out_clip[o0 + (unsigned)(r * n_frames)] =
@@ -934,7 +948,8 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     const int first_pad_tile = min(n_tiles, mode == kModeTorchVarlen
                                                 ? (1 + n_valid / kHop + kTileFrames - 1) / kTileFrames
                                                 : (n_valid + kNfft / 2 + kHop * kTileFrames - 1) / (kHop * kTileFrames));
-    const int pad_frame = min(n_frames, first_pad_tile * kTileFrames);         // first frame of the constant region
+    // first frame of the constant region (a multiple of 4)
+    const int pad_frame = whisper_const_frame(n_valid, n_frames, min(n_frames, first_pad_tile * kTileFrames), mode);
     const int key_frames = mode == kModeTorchVarlen ? 1 + n_valid / kHop : n_frames;   // frames that hold data
     // scaled clips (see kernel 1): keys are log10 of the unscaled energies, stored values carry the bias c / 4 with
     // c = 2 log10(s); the zero padding is log10(1e-10) = -10 in the scaled domain, i.e. -10 - c in the keys' domain
@@ -966,24 +981,43 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
             ++nt;
         }
     float* __restrict__ o = out + (size_t)clip * n_mels * n_frames;
-    const int rows = (n_mels - row0 + row_step - 1) / row_step;
+    // the workgroup's rows: one block of consecutive mel rows (so that the line a row's padding shares with the start
+    // of the NEXT row belongs to the same workgroup, see the fill)
+    const int rows_per = (n_mels + row_step - 1) / row_step;
+    const int mel_lo = row0 * rows_per;
+    const int rows = max(0, min(rows_per, n_mels - mel_lo));
 
-    // ---- fill: rows are n_frames floats long, n_frames % 4 == 0, pad_frame % 4 == 0: aligned 16-byte stores
-    if (pad_frame < n_frames) {
-        const int quads = (n_frames - pad_frame) >> 2;
-        // the workgroup's rows x quads as one index space, so that every trip but the last keeps all 256 lanes busy
-        const int n_quads = rows * quads;
-        int r = threadIdx.x / quads, q = threadIdx.x - r * quads;
-        const int dr = blockDim.x / quads, dq = blockDim.x - dr * quads;
-        for (int item = threadIdx.x; item < n_quads; item += blockDim.x) {
-            const int mel = row0 + r * row_step;
-            const bool mmasked = ((mel < 64 ? melmask_lo >> mel : melmask_hi >> (mel - 64)) & 1ull);
-            const float c = mmasked ? 0.0f : pad_y;
-            reinterpret_cast<f32x4*>(o + (size_t)mel * n_frames + pad_frame)[q] = f32x4{c, c, c, c};
+    // ---- fill.  A row is n_frames floats = 12 000 B long, not a multiple of the 128-byte line, so the padding segment
+    // of every row begins and ends inside a line, and a partly written line costs the memory side a read-modify-write:
+    // with plain segment stores those two lines per row held the whole pass at 4.3 TB/s (tools/ubench/fill_rate.hip:
+    // 5.5 TB/s when they are simply left out).  Lanes are therefore mapped to ABSOLUTE 16-byte slots -- eight lanes per
+    // line -- and the lanes of a first / last line that lie outside the segment read what is there (the row's own last
+    // computed frames; the first frames of the workgroup's next row) and write it back, so that the line goes out
+    // whole: 4.9 TB/s.  Only the last row of a workgroup keeps a partial last line (it belongs to another workgroup).
+    if (pad_frame < n_frames && rows > 0) {
+        const int vq = (((n_frames - pad_frame) * 4 + 127) / 128 + 1) * 8;      // 16-byte slots per row, whole lines
+        const int n_slots = rows * vq;
+        int r = threadIdx.x / vq, v = threadIdx.x - r * vq;
+        const int dr = blockDim.x / vq, dv = blockDim.x - dr * vq;
+        const uintptr_t clip_base = reinterpret_cast<uintptr_t>(o);
+        for (int item = threadIdx.x; item < n_slots; item += blockDim.x) {
+            const int mel = mel_lo + r;
+            const uintptr_t start = clip_base + ((size_t)mel * n_frames + pad_frame) * 4;
+            const uintptr_t end = clip_base + ((size_t)mel * n_frames + n_frames) * 4;
+            const uintptr_t a = (start & ~(uintptr_t)127) + 16u * (uintptr_t)v;
+            if (a >= start && a < end) {
+                const bool mmasked = ((mel < 64 ? melmask_lo >> mel : melmask_hi >> (mel - 64)) & 1ull);
+                const float c = mmasked ? 0.0f : pad_y;
+                *reinterpret_cast<f32x4*>(a) = f32x4{c, c, c, c};
+            } else if ((a < start && a >= clip_base + (size_t)mel * n_frames * 4) ||
+                       (a >= end && a < ((end + 127) & ~(uintptr_t)127) && r + 1 < rows)) {
+                const f32x4 keep = *reinterpret_cast<const f32x4*>(a);          // computed cells of this workgroup's rows
+                *reinterpret_cast<f32x4*>(a) = keep;
+            }
             r += dr;
-            q += dq;
-            if (q >= quads) {
-                q -= quads;
+            v += dv;
+            if (v >= vq) {
+                v -= vq;
                 ++r;
             }
         }
@@ -994,7 +1028,7 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
                 if (w <= 0) continue;
                 for (int e = threadIdx.x; e < rows * w; e += blockDim.x) {
                     const int r = e / w, c = e - r * w;
-                    o[(size_t)(row0 + r * row_step) * n_frames + a + c] = 0.0f;
+                    o[(size_t)(mel_lo + r) * n_frames + a + c] = 0.0f;
                 }
             }
         }
@@ -1023,7 +1057,7 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
                 const int ti = item / per_tile, rem = item - ti * per_tile;
                 const int r = rem / kQuadsPerTile, qt = rem - r * kQuadsPerTile;
                 const int fr = s_tiles[ti] * kTileFrames + 4 * qt;
-                melv[i] = row0 + r * row_step;
+                melv[i] = mel_lo + r;
                 if (fr < pad_frame) {                              // pad_frame is a multiple of 4
                     fr0[i] = fr;
                     v[i] = *reinterpret_cast<const f32x4*>(o + (size_t)melv[i] * n_frames + fr);

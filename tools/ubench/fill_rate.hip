@@ -57,6 +57,104 @@ __global__ __launch_bounds__(256) void fill_d(float* out, const int* pad_frame, 
         if (q >= q0) o[q] = f32x4{-0.6f, -0.6f, -0.6f, -0.6f};
 }
 
+// as fill_e<4> but only the whole 128-byte lines of each row segment are written (head / tail partial lines skipped):
+// tells whether the partial lines at the segment ends (row pitch 12000 B is not a multiple of 128) cost the rate
+__global__ void fill_g(float* out, const int* pad_frame, int M, int T, int align_bytes) {
+    const int clip = blockIdx.y, mel0 = blockIdx.x * 4;
+    const int pf = pad_frame[clip];
+    for (int r = 0; r < 4; ++r) {
+        if (mel0 + r >= M) break;
+        const size_t b0 = (((size_t)clip * M + mel0 + r) * T + pf) * 4, b1 = (((size_t)clip * M + mel0 + r) * T + T) * 4;
+        const size_t a0 = (b0 + align_bytes - 1) / align_bytes * align_bytes, a1 = b1 / align_bytes * align_bytes;
+        f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(out) + a0);
+        const int quads = (int)((a1 - a0) >> 4);
+        for (int q = threadIdx.x; q < quads; q += blockDim.x) o[q] = f32x4{-0.6f, -0.6f, -0.6f, -0.6f};
+    }
+}
+
+// the whole segment of every row, lanes mapped to ABSOLUTE 16-byte slots so that every 8 lanes write one 128-byte
+// line (head / tail lines masked): rows x virtual quads as one index space, as whisper_clamp_fill_kernel walks it
+__global__ __launch_bounds__(256) void fill_h(float* out, const int* pad_frame, int M, int T) {
+    const int clip = blockIdx.y, row0 = blockIdx.x, step = gridDim.x;
+    const int pf = pad_frame[clip];
+    const int rows = (M - row0 + step - 1) / step;
+    const int vq = (((T - pf) * 4 + 127) / 128 + 1) * 8;
+    const int n = rows * vq;
+    int r = threadIdx.x / vq, v = threadIdx.x - r * vq;
+    const int dr = blockDim.x / vq, dv = blockDim.x - dr * vq;
+    const uintptr_t base = reinterpret_cast<uintptr_t>(out + (size_t)clip * M * T);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int mel = row0 + r * step;
+        const uintptr_t start = base + ((size_t)mel * T + pf) * 4, end = base + ((size_t)mel * T + T) * 4;
+        const uintptr_t a = (start & ~(uintptr_t)127) + 16 * (uintptr_t)v;
+        if (a >= start && a < end) *reinterpret_cast<f32x4*>(a) = f32x4{-0.6f, -0.6f, -0.6f, -0.6f};
+        r += dr; v += dv;
+        if (v >= vq) { v -= vq; ++r; }
+    }
+}
+
+// as fill_h, but the lanes of a head / tail line that lie OUTSIDE the segment read what is there and write it back,
+// so that every line reaches memory as one whole-line write (no partial-line read-modify-write at the DRAM side)
+__global__ __launch_bounds__(256) void fill_i(float* out, const int* pad_frame, int M, int T, size_t total_bytes) {
+    const int clip = blockIdx.y, row0 = blockIdx.x, step = gridDim.x;
+    const int pf = pad_frame[clip];
+    const int rows = (M - row0 + step - 1) / step;
+    const int vq = (((T - pf) * 4 + 127) / 128 + 1) * 8;
+    const int n = rows * vq;
+    int r = threadIdx.x / vq, v = threadIdx.x - r * vq;
+    const int dr = blockDim.x / vq, dv = blockDim.x - dr * vq;
+    const uintptr_t buf0 = reinterpret_cast<uintptr_t>(out), buf1 = buf0 + total_bytes;
+    const uintptr_t base = reinterpret_cast<uintptr_t>(out + (size_t)clip * M * T);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int mel = row0 + r * step;
+        const uintptr_t start = base + ((size_t)mel * T + pf) * 4, end = base + ((size_t)mel * T + T) * 4;
+        const uintptr_t a = (start & ~(uintptr_t)127) + 16 * (uintptr_t)v;
+        const uintptr_t line_end = (end + 127) & ~(uintptr_t)127;
+        if (a < line_end && a >= buf0 && a + 16 <= buf1) {
+            f32x4 val = {-0.6f, -0.6f, -0.6f, -0.6f};
+            if (a < start || a >= end) val = *reinterpret_cast<const f32x4*>(a);
+            *reinterpret_cast<f32x4*>(a) = val;
+        }
+        r += dr; v += dv;
+        if (v >= vq) { v -= vq; ++r; }
+    }
+}
+
+// as fill_i in two passes: (1) the head and tail lines of all of the workgroup's rows (16 lanes per row: read what lies
+// outside the segment, write the whole line), (2) the whole lines in between, no loads
+__global__ __launch_bounds__(256) void fill_j(float* out, const int* pad_frame, int M, int T, size_t total_bytes) {
+    const int clip = blockIdx.y, row0 = blockIdx.x, step = gridDim.x;
+    const int pf = pad_frame[clip];
+    const int rows = (M - row0 + step - 1) / step;
+    const uintptr_t buf0 = reinterpret_cast<uintptr_t>(out), buf1 = buf0 + total_bytes;
+    const uintptr_t base = reinterpret_cast<uintptr_t>(out + (size_t)clip * M * T);
+    for (int i = threadIdx.x; i < rows * 16; i += blockDim.x) {
+        const int r = i >> 4, l = i & 15, mel = row0 + r * step;
+        const uintptr_t start = base + ((size_t)mel * T + pf) * 4, end = base + ((size_t)mel * T + T) * 4;
+        const uintptr_t line = l < 8 ? (start & ~(uintptr_t)127) : (end & ~(uintptr_t)127);
+        const uintptr_t a = line + 16 * (uintptr_t)(l & 7);
+        const bool aligned_end = (l >= 8) && ((end & 127) == 0);           // no tail line
+        const bool same = (l >= 8) && ((start & ~(uintptr_t)127) == (end & ~(uintptr_t)127));
+        if (!aligned_end && !same && a >= buf0 && a + 16 <= buf1) {
+            f32x4 val = {-0.6f, -0.6f, -0.6f, -0.6f};
+            if (a < start || a >= end) val = *reinterpret_cast<const f32x4*>(a);
+            *reinterpret_cast<f32x4*>(a) = val;
+        }
+    }
+    const int vq = (((T - pf) * 4) / 128) * 8;                           // upper bound of the whole lines of a row, in quads
+    const int n = rows * vq;
+    int r = threadIdx.x / vq, v = threadIdx.x - r * vq;
+    const int dr = blockDim.x / vq, dv = blockDim.x - dr * vq;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int mel = row0 + r * step;
+        const uintptr_t start = base + ((size_t)mel * T + pf) * 4, end = base + ((size_t)mel * T + T) * 4;
+        const uintptr_t a = ((start + 127) & ~(uintptr_t)127) + 16 * (uintptr_t)v;
+        if (a + 16 <= (end & ~(uintptr_t)127)) *reinterpret_cast<f32x4*>(a) = f32x4{-0.6f, -0.6f, -0.6f, -0.6f};
+        r += dr; v += dv;
+        if (v >= vq) { v -= vq; ++r; }
+    }
+}
+
 // R consecutive rows per workgroup, TPB threads, rows written one after the other
 template <int R>
 __global__ void fill_e(float* out, const int* pad_frame, int M, int T) {
@@ -118,6 +216,22 @@ int main(int argc, char** argv) {
         snprintf(nm, 64, "E R=2 tpb=%d", tpb); time(nm, [&] { hipLaunchKernelGGL(fill_e<2>, dim3(M / 2, B), dim3(tpb), 0, 0, out, pf, M, T); });
         snprintf(nm, 64, "E R=4 tpb=%d", tpb); time(nm, [&] { hipLaunchKernelGGL(fill_e<4>, dim3(M / 4, B), dim3(tpb), 0, 0, out, pf, M, T); });
         snprintf(nm, 64, "E R=8 tpb=%d", tpb); time(nm, [&] { hipLaunchKernelGGL(fill_e<8>, dim3(M / 8, B), dim3(tpb), 0, 0, out, pf, M, T); });
+    }
+    for (int al : {16, 64, 128, 256, 1024}) {
+        char nm[64]; snprintf(nm, 64, "G R=4 tpb=256 whole %d-byte blocks only", al);
+        time(nm, [&] { hipLaunchKernelGGL(fill_g, dim3(M / 4, B), dim3(256), 0, 0, out, pf, M, T, al); });
+    }
+    for (int split : {16, 32, 64}) {
+        char nm[64]; snprintf(nm, 64, "H split=%d line-aligned lanes, whole segment", split);
+        time(nm, [&] { hipLaunchKernelGGL(fill_h, dim3(split, B), dim3(256), 0, 0, out, pf, M, T); });
+    }
+    for (int split : {16, 32}) {
+        char nm[64]; snprintf(nm, 64, "I split=%d whole-line writes (read + rewrite)", split);
+        time(nm, [&] { hipLaunchKernelGGL(fill_i, dim3(split, B), dim3(256), 0, 0, out, pf, M, T, (size_t)B * M * T * 4); });
+    }
+    for (int split : {16, 32}) {
+        char nm[64]; snprintf(nm, 64, "J split=%d boundary lines first, then whole lines", split);
+        time(nm, [&] { hipLaunchKernelGGL(fill_j, dim3(split, B), dim3(256), 0, 0, out, pf, M, T, (size_t)B * M * T * 4); });
     }
     const size_t n4 = bytes / 16;
     for (int g : {1024, 4096, 16384, 65536}) {
