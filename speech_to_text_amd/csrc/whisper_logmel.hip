@@ -449,6 +449,10 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         if (first >= 0 && first + 5 * kHop + kNfft <= n_valid) {
 #pragma unroll
             for (int m = 0; m < 28; ++m) r[m] = x[base + 20 * m];
+        } else if (mode != kModeTorchVarlen && first >= n_valid && first + 5 * kHop + kNfft <= kMaxSamples) {
+            // the whole pass lies in the zero padding to 30 s (about half of the passes of a short clip's last tile)
+#pragma unroll
+            for (int m = 0; m < 28; ++m) r[m] = 0.0f;
         } else {
 #pragma unroll
             for (int m = 0; m < 28; ++m) {
