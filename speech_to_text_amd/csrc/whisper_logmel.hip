@@ -607,8 +607,9 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     for (int r = 0; r < 4; ++r) o_r[r] = (unsigned)(((lane >> 4) * 4 + r) * n_frames + (lane & 15));
 #ifdef STTFE_STAMPS
     // slots 0-9: phases of the tile loop; 10: kernel entry -> item loop; 11: item switches (end of an item's last tile
-    // -> start of the next item's first tile, empty items included); 12: after the last item; 13 / 14: entry / exit time
-    unsigned long long stamp_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = stamp_entry;
+    // -> start of the next item's first tile, empty items included); 12: after the last item; 13 / 14: entry / exit time;
+    // 16: item tail + ticket hand-over barrier; 17: item decode
+    unsigned long long stamp_sum[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = stamp_entry;
     STAMP(10);
 #endif
 
@@ -889,7 +890,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
       __syncthreads();
       const int after_next = (int)min(*slot, (unsigned)n_items);
 #ifdef STTFE_STAMPS
-      STAMP(1);       // diagnostic: end of the item's last tile -> ticket hand-over barrier passed
+      STAMP(16);      // diagnostic: end of the item's last tile -> ticket hand-over barrier passed
 #endif
       ++iter;
       item = next_item;
@@ -898,7 +899,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
       next_item = after_next;
       if (next_item < n_items) decode(next_item, clip_nx, run_nx);
 #ifdef STTFE_STAMPS
-      STAMP(9);       // diagnostic: item decode
+      STAMP(17);      // diagnostic: item decode
 #endif
       len_cur = len_next;
       off_cur = off_next;
@@ -908,8 +909,8 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         STAMP(12);
         stamp_sum[13] = stamp_entry;
         stamp_sum[14] = stamp_prev;
-        unsigned long long* dst = g_stamp_buf + ((size_t)blockIdx.x * kWaves + wave) * 16;
-        for (int i = 0; i < 16; ++i) dst[i] = stamp_sum[i];
+        unsigned long long* dst = g_stamp_buf + ((size_t)blockIdx.x * kWaves + wave) * 20;
+        for (int i = 0; i < 20; ++i) dst[i] = stamp_sum[i];
     }
 #endif
 }
