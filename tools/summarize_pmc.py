@@ -25,7 +25,7 @@ out = {
     "note": "FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a streaming read "
             "(MI355X_MICROARCH.md, HBM) -> read bytes = FETCH_SIZE * 1024 * 2",
     "counters": {k: {c: {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)} for c, v in sorted(cs.items())}
-                 for k, cs in sorted(acc.items()) if "whisper" in k or "kaldi" in k or "resample" in k or "normalize" in k},
+                 for k, cs in sorted(acc.items()) if any(t in k for t in ("whisper", "kaldi", "resample", "decimate", "copy_peak", "normalize", "trim", "waveform", "pv_"))},
 }
 json.dump(out, open(dst, "w"), indent=1)
 for k, cs in out["counters"].items():
