@@ -27,10 +27,13 @@ traffic = HBM bytes per launch from the rocprofv3 PMC passes committed under pro
 + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md), when that file covers the workload.
 cpu_baseline: the reference's CPU extractor (HF, torch-CPU path) on a bounded sample of the same
 workload, rank 0, N = 1 only.
+--streams n (default 1): n batches in flight on n HIP streams; a serial timed region runs first (kernel timings,
+serial_ms_per_step), then the same K steps pipelined (ms_per_step and value).  DESIGN.md section 5.0 has the lines.
 """
 from __future__ import annotations
 
 import argparse
+import contextlib
 import ctypes
 import json
 import os
@@ -212,6 +215,11 @@ def main():
     ap.add_argument("--settle-seconds", type=float, default=1.0,
                     help="untimed steps run after the W warm-up steps until this much wall time has passed: the GPU "
                          "clocks of the pool's boxes take ~30 launches to settle (1.20 -> 1.02 ms per launch)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="n > 1: consecutive steps go round-robin to n HIP streams, each with an output tensor of its own "
+                         "(a serving loop with n batches in flight): the memory-bound kernels of one batch (resample, "
+                         "clamp / fill, CMVN) run under the issue-bound feature kernel of the next.  `value` is then the "
+                         "pipelined rate; the kernel timings of `roofline` come from a serial timed region run first")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -268,6 +276,13 @@ def main():
         corpus_lens = all_lens[mine]
     n_mels = 128 if wl == "whisper128_aug" else 80
     extra_kernels = []
+    n_slots = max(args.streams, 1)
+    side = [torch.cuda.Stream(device) for _ in range(n_slots)] if n_slots > 1 else []
+    pipelined = [False]                    # switched on for the pipelined timed region only
+
+    def stream_of(k):
+        return torch.cuda.stream(side[k]) if pipelined[0] else contextlib.nullcontext()
+
     step_bytes = None                      # algorithmic bytes of a whole step when they differ from the dominant kernel's
 
     # ------- synthetic inputs resident in HBM (clip-sharded corpus: rank r owns its own B clips) -------
@@ -300,18 +315,23 @@ def main():
         # this rank's shard of the corpus, chunk by chunk; features of a chunk overwrite the previous chunk's
         # (an offline precompute would hand them to the writer here)
         fe = HipWhisperFeatureExtractor(n_mels, device=device)
-        out = torch.empty((B, n_mels, 3000), dtype=torch.float32, device=device)
+        outs = [torch.empty((B, n_mels, 3000), dtype=torch.float32, device=device) for _ in range(n_slots)]
         kernel, kname = "whisper_stft_mel", "whisper_stft_mel_kernel"
         n_local = len(lens)
         bytes_per_launch = float(4 * np.minimum(lens, N_SAMPLES).sum() + 4 * n_mels * 3000 * n_local)   # per pass over the shard
 
-        def step():
+        chunk = [0]
+
+        def step(slot=0):
             for c0 in range(0, n_local, B):
                 c1 = min(c0 + B, n_local)
-                fe.extract(pcm, offsets[c0:c1], lengths[c0:c1], out=out[:c1 - c0])
+                k = chunk[0] % n_slots                       # n_slots > 1: the chunks are the batches in flight
+                chunk[0] += 1
+                with stream_of(k):
+                    fe.extract(pcm, offsets[c0:c1], lengths[c0:c1], out=outs[k][:c1 - c0])
     elif wl in ("whisper80", "resample_whisper", "whisper128_aug"):
         fe = HipWhisperFeatureExtractor(n_mels, device=device)
-        out = torch.empty((B, n_mels, 3000), dtype=torch.float32, device=device)
+        outs = [torch.empty((B, n_mels, 3000), dtype=torch.float32, device=device) for _ in range(n_slots)]
         kernel, kname = "whisper_stft_mel", "whisper_stft_mel_kernel"
         valid16 = np.minimum(lens // (3 if sr == 48000 else 1), N_SAMPLES)
         bytes_per_launch = float(4 * valid16.sum() + 4 * n_mels * 3000 * B)
@@ -320,14 +340,14 @@ def main():
             # int16 PCM) + the feature tensor; the 16 kHz intermediate is not algorithmic traffic
             step_bytes = float((2 if s16 else 4) * lens.sum() + 4 * n_mels * 3000 * B)
         if wl == "whisper80":
-            step = lambda: fe.extract(pcm, offsets, lengths, out=out)
+            step = lambda slot=0: fe.extract(pcm, offsets, lengths, out=outs[slot])
         elif wl == "whisper128_aug":
             sampler = SpecAugmentSampler(AugmentationConfig(enabled=True))
             torch.manual_seed(104)
             import random
             random.seed(104)
             table = sampler.mask_table([(n_mels, 3000)] * B).to(device)      # drawn once: RNG is host work
-            step = lambda: fe.extract(pcm, offsets, lengths, mask_table=table, out=out)
+            step = lambda slot=0: fe.extract(pcm, offsets, lengths, mask_table=table, out=outs[slot])
         else:
             pre = GpuAudioPreprocessor(normalize=True, trim_silence=False, min_duration=0.0, max_duration=1e9,
                                        device=device)
@@ -337,25 +357,34 @@ def main():
                 # rows P2 + W fused: the normalise pass disappears into the feature kernel's epilogue
                 extra_kernels = ["resample_peak"]
 
-                def step():
+                def step(slot=0):
                     p = pre.run(pcm, offsets, lengths, host_lens, 1, 48000, defer_normalize=True)
-                    fe.extract(p.pcm, p.offsets, p.lengths, out=out, clip_scale=p.scale)
+                    fe.extract(p.pcm, p.offsets, p.lengths, out=outs[slot], clip_scale=p.scale)
             else:
-                def step():
+                def step(slot=0):
                     p = pre.run(pcm, offsets, lengths, host_lens, 1, 48000)
-                    fe.extract(p.pcm, p.offsets, p.lengths, out=out)
+                    fe.extract(p.pcm, p.offsets, p.lengths, out=outs[slot])
     else:
         fe = HipSpeech2TextFeatureExtractor(device=device, stft_precision="float32" if s2t_f32 else "float64")
         t_max = max(fe.num_frames(n) for n in host_lens)
         kernel, kname = "kaldi_fbank", ("kaldi_fbank_kernel" if s2t_f32 else "kaldi_fbank64_kernel")
         extra_kernels = ["kaldi_cmvn"]
         bytes_per_launch = float(4 * lens.sum() + (4 * 80 + 4) * t_max * B)
-        step = lambda: fe.extract(pcm, offsets, lengths, t_max)
+        step = lambda slot=0: fe.extract(pcm, offsets, lengths, t_max)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def run_steps(n):
+        if wl == "corpus" or not pipelined[0]:
+            for _ in range(n):
+                step()                                   # corpus: the chunks pick their own streams
+        else:
+            for i in range(n):
+                with stream_of(i % n_slots):
+                    step(i % n_slots)
 
     # The event pool is created before the warm-up (and parked with a huge stride): creating it between the settle
     # phase and the timed region left the GPU idle for 2 ms, after which the next ~15 launches ran up to 10 % slower
@@ -393,14 +422,25 @@ def main():
     _lib.check(L.sttfe_timing_set_stride(max(args.event_stride, 1)))
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = serial_elapsed = time.perf_counter() - t0
+    if n_slots > 1:
+        # the pipelined timed region: no events (a pair drains the queues around its launch), a few untimed steps to
+        # fill the pipeline, then the same K steps round-robin over the streams
+        _lib.check(L.sttfe_timing_set_stride(1 << 30))
+        pipelined[0] = True
+        run_steps(max(2 * n_slots, 4))
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        pipelined[0] = False
     if dist is not None:
-        t = torch.tensor([elapsed, cold_elapsed], dtype=torch.float64, device=red_device)
+        t = torch.tensor([elapsed, cold_elapsed, serial_elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, cold_elapsed = float(t[0].item()), float(t[1].item())
+        elapsed, cold_elapsed, serial_elapsed = float(t[0].item()), float(t[1].item()), float(t[2].item())
         a = torch.tensor([audio_seconds], dtype=torch.float64, device=red_device)
         dist.all_reduce(a, op=dist.ReduceOp.SUM)
         audio_total = float(a.item())
@@ -446,6 +486,8 @@ def main():
             "settle_s": args.settle_seconds,
             "ms_per_step": elapsed / args.steps * 1e3,
             "cold_ms_per_step": cold_elapsed / args.steps * 1e3,
+            "streams": n_slots,
+            "serial_ms_per_step": serial_elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong" if wl == "corpus" else "weak",
             "vs_baseline": None,
