@@ -19,6 +19,9 @@ max-over-ranks time.
   whisper128_aug    configs[3]: Whisper 128-mel + SpecAugment masks, Common-Voice-length clips, batch 1024
   corpus            configs[4]: offline precompute of a 30 000-clip (~43 h) Common-Voice-length corpus, clip i on rank
                     i mod G, chunks of 1024 clips, Whisper-80 features (strong scaling: the corpus is fixed)
+  corpus_compact    the same corpus under the compact output contract of the feature cache: chunks in order of length,
+                    each extracted with n_frames = whisper_compact_frames(chunk) (its columns are bit-identical to the
+                    30 s tensor's, the rest is one constant per clip and is not written)
 
 roofline: dominant kernel of the workload; achieved = algorithmic bytes per launch (SURVEY.md section 8d:
 input PCM needed + output written, each once) / its average launch duration, measured with HIP events
@@ -201,7 +204,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="whisper80",
-                    choices=["whisper80", "s2t", "s2t_f32", "resample_whisper", "resample_whisper_s16", "whisper128_aug", "corpus"])
+                    choices=["whisper80", "s2t", "s2t_f32", "resample_whisper", "resample_whisper_s16", "whisper128_aug", "corpus", "corpus_compact"])
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (0 = the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fused-normalize", action="store_true",
@@ -266,6 +269,9 @@ def main():
     s2t_f32 = wl == "s2t_f32"
     if s2t_f32:
         wl = "s2t"
+    compact = wl == "corpus_compact"
+    if compact:
+        wl = "corpus"
     seed = {"whisper80": 101, "s2t": 102, "resample_whisper": 103, "whisper128_aug": 104, "corpus": 105}[wl] * 1000 + rank
     rng = np.random.default_rng(seed)
     B = args.batch or {"whisper80": 1024, "s2t": 256, "resample_whisper": 512, "whisper128_aug": 1024, "corpus": 1024}[wl]
@@ -274,6 +280,10 @@ def main():
         all_lens = common_voice_lengths(np.random.default_rng(105), 30000)          # the same corpus on every rank
         mine = shard_indices(30000, rank, world)
         corpus_lens = all_lens[mine]
+        if compact:
+            # the compact output contract: this rank's clips in order of length (host metadata, known before the pass),
+            # every chunk extracted with n_frames = whisper_compact_frames(chunk) instead of 3000
+            corpus_lens = np.sort(corpus_lens, kind="stable")
     n_mels = 128 if wl == "whisper128_aug" else 80
     extra_kernels = []
     n_slots = max(args.streams, 1)
@@ -318,8 +328,13 @@ def main():
         outs = [torch.empty((B, n_mels, 3000), dtype=torch.float32, device=device) for _ in range(n_slots)]
         kernel, kname = "whisper_stft_mel", "whisper_stft_mel_kernel"
         n_local = len(lens)
-        bytes_per_launch = float(4 * np.minimum(lens, N_SAMPLES).sum() + 4 * n_mels * 3000 * n_local)   # per pass over the shard
-
+        if compact:
+            from speech_to_text_amd.feature_cache import whisper_compact_frames
+            chunk_T = {c0: whisper_compact_frames(host_lens[c0:c0 + B]) for c0 in range(0, n_local, B)}
+        else:
+            chunk_T = {c0: 3000 for c0 in range(0, n_local, B)}
+        out_cols = sum(T * (min(c0 + B, n_local) - c0) for c0, T in chunk_T.items())
+        bytes_per_launch = float(4 * np.minimum(lens, N_SAMPLES).sum() + 4 * n_mels * out_cols)   # per pass over the shard
         chunk = [0]
 
         def step(slot=0):
@@ -327,8 +342,10 @@ def main():
                 c1 = min(c0 + B, n_local)
                 k = chunk[0] % n_slots                       # n_slots > 1: the chunks are the batches in flight
                 chunk[0] += 1
+                T = chunk_T[c0]
                 with stream_of(k):
-                    fe.extract(pcm, offsets[c0:c1], lengths[c0:c1], out=outs[k][:c1 - c0])
+                    fe.extract(pcm, offsets[c0:c1], lengths[c0:c1],
+                               out=outs[k].view(-1)[:(c1 - c0) * n_mels * T].view(c1 - c0, n_mels, T))
     elif wl in ("whisper80", "resample_whisper", "whisper128_aug"):
         fe = HipWhisperFeatureExtractor(n_mels, device=device)
         outs = [torch.empty((B, n_mels, 3000), dtype=torch.float32, device=device) for _ in range(n_slots)]
@@ -475,7 +492,9 @@ def main():
                   "s2t": f"BASELINE configs[1]: Speech2Text fbank + utterance CMVN, {B} ragged 2-10 s clips, dynamic padding",
                   "resample_whisper": f"BASELINE configs[2]: 48 kHz PCM -> resample + peak normalise -> Whisper 80-mel, {B} clips",
                   "whisper128_aug": f"BASELINE configs[3]: Whisper 128-mel + SpecAugment masks, {B} clips",
-                  "corpus": f"BASELINE configs[4]: 30 000-clip (~43 h) corpus, clip i on rank i mod {world}, chunks of {B}"}
+                  "corpus": f"BASELINE configs[4]: 30 000-clip (~43 h) corpus, clip i on rank i mod {world}, chunks of {B}"
+                            + (" in order of length, compact output (frames + padding constant per clip, no 30 s padding written)"
+                               if compact else "")}
         result = {
             "metric": names[wl],
             "value": audio_total * args.steps / elapsed,

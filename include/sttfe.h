@@ -71,6 +71,12 @@ int sttfe_whisper_workspace_bytes(int batch, size_t* bytes);
  * pcm/offsets/lengths : device; clips at 16 kHz; samples past lengths[b] (up to 480000) count as 0,
  *                       samples past 480000 are ignored (HF pad/truncate to 30 s).
  * out                 : device float32 [batch][n_mels][n_frames], n_frames = 3000 for HF parity.
+ *                       Compact output (callers that keep "frames + padding constant", e.g. a feature cache): any
+ *                       multiple of 4 with 160 * n_frames >= lengths[b] + 200 + 4 * 160 for every clip gives columns
+ *                       bit-identical to the first n_frames of the 3000-frame result, the last 4 of them padding for
+ *                       every clip (out[b][0][n_frames - 1] is clip b's padding constant); the 30 s padding behind them
+ *                       is then neither computed nor written.  The caller guarantees the bound (it is not checked:
+ *                       a longer clip is the HF extractor run with n_samples = 160 * n_frames).
  * mask_tbl            : device int32 [batch][n_masks][3] = {axis, start, end} or NULL; elements
  *                       with start <= index < end along the axis are set to 0.0 AFTER the
  *                       log/clamp/scale (SpecAugment, src/data.py:185-194); rows with end<=start

@@ -41,6 +41,16 @@ def whisper_computed_frames(n_samples: int, n_frames: int = 3000) -> int:
     return min(n_frames, max(tiles, 1) * _TILE)
 
 
+def whisper_compact_frames(n_samples: Sequence[int], n_frames: int = 3000) -> int:
+    """Smallest ``n_frames`` for ``HipWhisperFeatureExtractor.extract(..., n_frames=)`` whose columns equal the 30 s
+    result's for every clip of the batch AND whose last 4 columns are padding for every clip: frame t covers samples
+    [160 t - 200, 160 t + 200), so clip b is constant from frame ceil((n_b + 200) / 160) on; rounded up to the
+    kernel's 4-column groups, plus one group.  ``min(n_frames, .)``: a 30 s clip has no padding column."""
+    n = max([0] + [min(int(v), _HOP * n_frames) for v in n_samples])
+    first_const = (n + _NFFT // 2 + _HOP - 1) // _HOP
+    return min(n_frames, (first_const + 3) // 4 * 4 + 4)
+
+
 class FeatureCacheWriter:
     def __init__(self, directory: str, model_type: str, n_mels: int, n_frames: int = 3000, shard_clips: int = 1024,
                  rank: int = 0):
@@ -72,7 +82,9 @@ class FeatureCacheWriter:
         frame counts (Speech2Text; default: all T)."""
         B = int(features.shape[0])
         if self.model_type == "whisper":
-            keep = [whisper_computed_frames(n, self.n_frames) for n in n_samples]
+            # a compact batch (extract(..., n_frames=whisper_compact_frames(lengths))) has fewer columns than 3000:
+            # its last column is still every clip's padding constant
+            keep = [min(whisper_computed_frames(n, self.n_frames), int(features.shape[2])) for n in n_samples]
         else:
             keep = [int(f) for f in (frames if frames is not None else [features.shape[2]] * B)]
         t_max = max(keep) if keep else 0

@@ -175,8 +175,15 @@ class HipWhisperFeatureExtractor:
 
     def extract(self, pcm: torch.Tensor, offsets: torch.Tensor, lengths: torch.Tensor,
                 mask_table: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                clip_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+                clip_scale: Optional[torch.Tensor] = None, n_frames: Optional[int] = None) -> torch.Tensor:
         """Device-resident entry: packed PCM + per-clip offsets/lengths -> (B, M, 3000) float32.
+
+        ``n_frames`` (a multiple of 4, default 3000): the COMPACT output contract for callers that keep "frames + padding
+        constant" instead of the 30 s tensor (the offline feature cache): only the first ``n_frames``
+        columns are produced.  They are bit-identical to the same columns of the 3000-frame result as long as every
+        clip's audio ends before them -- ``n_frames >= whisper_compact_frames(lengths)``, which the caller guarantees
+        (it knows the lengths on the host; the last 4 columns are then padding for every clip, so ``out[b, 0, -1]`` is
+        clip b's padding constant).  A shorter ``n_frames`` is the HF extractor run with that ``n_samples``.
 
         ``clip_scale`` (device float32 (B,)): the features of ``clip_scale[b] * clip_b`` without touching the
         samples (``sttfe_whisper_logmel_scaled``) -- the peak normalisation of ``GpuAudioPreprocessor.run(...,
@@ -184,8 +191,15 @@ class HipWhisperFeatureExtractor:
         device = pcm.device
         B = int(offsets.shape[0])
         L = _lib.lib()
+        if n_frames is None:
+            n_frames = int(out.shape[2]) if (out is not None and out.dim() == 3) else self.nb_max_frames
+        T = int(n_frames)
+        if T < 4 or T > self.nb_max_frames or T % 4:
+            raise ValueError(f"n_frames must be a multiple of 4 in [4, {self.nb_max_frames}], got {n_frames}")
         if out is None:
-            out = torch.empty((B, self.feature_size, self.nb_max_frames), dtype=torch.float32, device=device)
+            out = torch.empty((B, self.feature_size, T), dtype=torch.float32, device=device)
+        elif tuple(out.shape) != (B, self.feature_size, T) or not out.is_contiguous() or out.dtype != torch.float32:
+            raise ValueError(f"out must be a contiguous float32 tensor of shape {(B, self.feature_size, T)}")
         ws_bytes = ctypes.c_size_t()
         _lib.check(L.sttfe_whisper_workspace_bytes(B, ctypes.byref(ws_bytes)))
         ws = torch.empty(max(ws_bytes.value, 1), dtype=torch.uint8, device=device)
@@ -198,7 +212,7 @@ class HipWhisperFeatureExtractor:
         with torch.cuda.device(device):
             if clip_scale is None:
                 _lib.check(L.sttfe_whisper_logmel(_lib.ptr(pcm), _lib.ptr(offsets), _lib.ptr(lengths), B,
-                                                  self.feature_size, self.nb_max_frames,
+                                                  self.feature_size, T,
                                                   _lib.ptr(self._tables_on(device)), _lib.ptr(out),
                                                   _lib.ptr(mask_table), n_masks, _lib.ptr(ws), ws.numel(),
                                                   ctypes.c_void_p(stream)), "sttfe_whisper_logmel")
@@ -207,7 +221,7 @@ class HipWhisperFeatureExtractor:
                     raise ValueError("clip_scale must be a float32 tensor of B elements on the PCM's device")
                 clip_scale = clip_scale.contiguous()
                 _lib.check(L.sttfe_whisper_logmel_scaled(_lib.ptr(pcm), _lib.ptr(offsets), _lib.ptr(lengths), B,
-                                                         self.feature_size, self.nb_max_frames,
+                                                         self.feature_size, T,
                                                          _lib.ptr(self._tables_on(device)), _lib.ptr(out),
                                                          _lib.ptr(mask_table), n_masks, _lib.ptr(clip_scale),
                                                          _lib.ptr(ws), ws.numel(), ctypes.c_void_p(stream)),

@@ -72,13 +72,19 @@ def all_gather_features(local: torch.Tensor, owned: Sequence[int], n_total: int,
 
 
 def precompute_corpus(lengths: Sequence[int], rank: int, world_size: int, chunk: int,
-                      extract: Callable[[List[int]], object], balanced: bool = True) -> Iterable[Tuple[List[int], object]]:
+                      extract: Callable[[List[int]], object], balanced: bool = True,
+                      by_length: bool = False) -> Iterable[Tuple[List[int], object]]:
     """Offline feature precompute driver (BASELINE config 5): this rank's clips in chunks of ``chunk``.
 
     ``extract(indices)`` runs the front-end on those clips (whatever it returns is yielded with the
     indices).  With ``balanced`` the partition balances total samples, else it is round-robin.
+    ``by_length``: the rank's clips are chunked in order of length (ties by index), so that the clips of a chunk are
+    about equally long and a compact extraction (``extract(..., n_frames=whisper_compact_frames(chunk lengths))``)
+    writes next to no padding; the yielded indices say which clip is which.
     """
     mine = balanced_shards(lengths, world_size)[rank] if balanced else shard_indices(len(lengths), rank, world_size)
+    if by_length:
+        mine = sorted(mine, key=lambda i: (int(lengths[i]), i))
     for c0 in range(0, len(mine), chunk):
         idx = mine[c0:c0 + chunk]
         yield idx, extract(idx)

@@ -71,3 +71,64 @@ def test_unchunked_call_matches_the_oracle_on_a_sample(corpus):
     exp = whisper_features(clips, 80)
     got = full[torch.as_tensor(pick, device=DEV)].cpu().numpy()
     assert float(np.abs(got - exp).max()) <= 1e-4
+
+
+def test_compact_chunks_by_length_equal_the_30s_tensor(corpus, tmp_path):
+    """The compact output contract ("frames + padding constant" instead of the 30 s tensor): chunks in
+    order of length, each extracted with n_frames = whisper_compact_frames(chunk lengths).  Every column is bit-identical
+    to the 3000-frame result, everything behind it equals the chunk tensor's last column, and a feature cache written
+    from the compact chunks reads back exactly what one written from the full tensors does."""
+    from speech_to_text_amd.feature_cache import FeatureCacheDataset, FeatureCacheWriter, whisper_compact_frames
+    fe, lens, pcm2d, offsets, lengths, full = corpus
+    pcm = pcm2d.reshape(-1)
+    host_lens = [int(v) for v in lens]
+    w_compact = FeatureCacheWriter(str(tmp_path / "compact"), "whisper", 80)
+    w_full = FeatureCacheWriter(str(tmp_path / "full"), "whisper", 80)
+    frames_seen, order = [], []
+
+    def extract(idx):
+        T = whisper_compact_frames([host_lens[i] for i in idx])
+        frames_seen.append(T)
+        sel = torch.as_tensor(idx, dtype=torch.int64, device=DEV)
+        return fe.extract(pcm, offsets[sel], lengths[sel], n_frames=T)
+
+    for idx, feats in precompute_corpus(host_lens, 0, 1, CHUNK, extract, balanced=False, by_length=True):
+        sel = torch.as_tensor(idx, dtype=torch.int64, device=DEV)
+        T = feats.shape[2]
+        assert T % 4 == 0 and T < 3000
+        assert torch.equal(feats, full[sel][:, :, :T])
+        assert bool((full[sel][:, :, T:] == feats[:, :, -1:]).all())
+        pos = list(range(0, len(idx), 37))                            # a sample of the chunk goes to the two caches
+        keep = [idx[p] for p in pos]
+        w_compact.add_batch(keep, feats[pos], [host_lens[i] for i in keep])
+        w_full.add_batch(keep, full[torch.as_tensor(keep, dtype=torch.int64, device=DEV)], [host_lens[i] for i in keep])
+        order.extend(idx)
+    assert sorted(order) == list(range(N_CLIPS))
+    assert [host_lens[i] for i in order] == sorted(host_lens)          # chunks in order of length
+    assert frames_seen == sorted(frames_seen) and frames_seen[0] < frames_seen[-1]
+    w_compact.close()
+    w_full.close()
+    a, b = FeatureCacheDataset(str(tmp_path / "compact")), FeatureCacheDataset(str(tmp_path / "full"))
+    assert len(a) == len(b) > 10
+    for i in range(len(a)):
+        assert a[i]["id"] == b[i]["id"] and torch.equal(a[i]["input_features"], b[i]["input_features"])
+        assert torch.equal(a[i]["input_features"], full[a[i]["id"]].cpu())
+
+
+def test_compact_frames_rule_and_argument_checks(corpus):
+    from speech_to_text_amd.feature_cache import whisper_compact_frames
+    fe, lens, pcm2d, offsets, lengths, full = corpus
+    assert whisper_compact_frames([0]) == 8 and whisper_compact_frames([1]) == 8
+    assert whisper_compact_frames([160 * 4 - 200]) == 8 and whisper_compact_frames([160 * 4 - 199]) == 12
+    assert whisper_compact_frames([480000]) == 3000 and whisper_compact_frames([10, 500000]) == 3000
+    with pytest.raises(ValueError):
+        fe.extract(pcm2d.reshape(-1), offsets[:4], lengths[:4], n_frames=1002)
+    with pytest.raises(ValueError):
+        fe.extract(pcm2d.reshape(-1), offsets[:4], lengths[:4], n_frames=3004)
+    # the rule is tight at its boundary: clips cut to 160 k - 200 (+1) samples
+    for n in (160 * 50 - 200, 160 * 50 - 199, 37, 0):
+        ln = torch.tensor([n, n // 2], dtype=torch.int32, device=DEV)
+        T = whisper_compact_frames([n, n // 2])
+        ref = fe.extract(pcm2d.reshape(-1), offsets[:2], ln)
+        got = fe.extract(pcm2d.reshape(-1), offsets[:2], ln, n_frames=T)
+        assert torch.equal(got, ref[:, :, :T]) and bool((ref[:, :, T:] == got[:, :, -1:]).all()), n
