@@ -126,7 +126,7 @@ def test_compact_frames_rule_and_argument_checks(corpus):
     with pytest.raises(ValueError):
         fe.extract(pcm2d.reshape(-1), offsets[:4], lengths[:4], n_frames=3004)
     # the rule is tight at its boundary: clips cut to 160 k - 200 (+1) samples
-    for n in (160 * 50 - 200, 160 * 50 - 199, 37, 0):
+    for n in (160 * 52 - 200, 160 * 52 - 199, 160 * 50 - 199, 37, 0):
         ln = torch.tensor([n, n // 2], dtype=torch.int32, device=DEV)
         T = whisper_compact_frames([n, n // 2])
         ref = fe.extract(pcm2d.reshape(-1), offsets[:2], ln)

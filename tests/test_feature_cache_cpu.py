@@ -78,3 +78,34 @@ def test_augmented_features_are_refused(tmp_path):
     masked[0, :, 2000:2010] = 0.0                                   # time mask inside the padding
     with pytest.raises(ValueError, match="not constant behind"):
         w.add_batch([4, 5], masked, [8000, 8000])
+
+
+def test_compact_batches_round_trip_and_by_length_chunks(tmp_path):
+    """Compact batches (only whisper_compact_frames(lengths) columns, the last of them padding) read back as the same
+    30 s tensors as full batches; precompute_corpus(by_length=True) visits every clip once, shortest first."""
+    from speech_to_text_amd.feature_cache import whisper_compact_frames
+    from speech_to_text_amd.sharding import precompute_corpus
+    lens = [16000, 123456, 80000, 1, 7481, 160 * 52 - 200, 160 * 52 - 199]
+    assert whisper_compact_frames([160 * 52 - 200]) == 56 and whisper_compact_frames([160 * 52 - 199]) == 60
+    assert whisper_compact_frames([]) == 8 and whisper_compact_frames([480000, 3]) == 3000
+    full = fake_whisper(lens, seed=5)
+    for b, n in enumerate(lens):                       # constant from the first frame that sees no audio, as the kernel's
+        full[b, :, (n + 200 + 159) // 160:] = full[b, 0, -1]
+    seen = []
+
+    def extract(idx):
+        T = whisper_compact_frames([lens[i] for i in idx])
+        assert all((lens[i] + 200 + 159) // 160 + 4 <= T for i in idx) and T % 4 == 0
+        return full[idx][:, :, :T].clone()
+
+    wc, wf = FeatureCacheWriter(str(tmp_path / "c"), "whisper", 8), FeatureCacheWriter(str(tmp_path / "f"), "whisper", 8)
+    for idx, feats in precompute_corpus(lens, 0, 1, 3, extract, balanced=False, by_length=True):
+        wc.add_batch(idx, feats, [lens[i] for i in idx])
+        wf.add_batch(idx, full[idx], [lens[i] for i in idx])
+        seen.extend(idx)
+    wc.close(), wf.close()
+    assert [lens[i] for i in seen] == sorted(lens) and sorted(seen) == list(range(len(lens)))
+    a, b = FeatureCacheDataset(str(tmp_path / "c")), FeatureCacheDataset(str(tmp_path / "f"))
+    for i in range(len(lens)):
+        assert a[i]["id"] == b[i]["id"] == i
+        assert torch.equal(a[i]["input_features"], full[i]) and torch.equal(b[i]["input_features"], full[i])
