@@ -6,7 +6,9 @@
 // x / (max|x| + 1e-8) (:78-81), trim to the first..last sample above 0.01 * max (:84-91).
 //
 // Kernel 1a (decimate_peak<ORIG>): integer decimation ORIG:1 (48 -> 16 kHz: ORIG = 3, 41 taps;
-//   32 -> 16 kHz: ORIG = 2, 28 taps).  One 256-thread workgroup per 1024-output tile: the input span
+//   32 -> 16 kHz: ORIG = 2, 28 taps).  Persistent 256-thread workgroups walk (clip, run of 8 tiles) items,
+//   clip-major over an LDS prefix of the clips' run counts (up to 2048 clips; one item per workgroup
+//   beyond that).  Per 1024-output tile the input span
 //   is read from HBM once with lane-contiguous loads and de-interleaved into ORIG phase rows in LDS
 //   (row r holds padded[ORIG m + r]), so that out[i] = sum_r sum_j h[ORIG j + r] * row_r[i + j] and a
 //   thread that owns 4 consecutive outputs reads each row with five conflict-free ds_read_b128
@@ -21,6 +23,7 @@
 //   samples: every later kernel addresses a clip through the device offsets / lengths arrays.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/sttfe.h"
 #include "tables.h"
@@ -35,6 +38,7 @@ constexpr int kTile = kThreads * kOutPerThread;       // 1024 outputs per tile
 constexpr int kTapsPerPhase = 14;                     // ceil((2 width + ORIG) / ORIG) for every ORIG:1 ratio
 constexpr int kRowLen = kTile + 16;                   // m range a tile reads: 4 * 255 + 20
 constexpr int kRowStride = 1068;                      // words; % 4 == 0 (b128 alignment), % 32 == 12
+constexpr int kMaxPlanClips = 2048;                   // clips whose run-count prefix a persistent workgroup keeps in LDS
 static_assert(kRowStride >= kRowLen && kRowStride % 4 == 0, "phase row stride");
 }  // namespace rs
 
@@ -66,49 +70,111 @@ __global__ __launch_bounds__(rs::kThreads) void decimate_peak_kernel(
     const TIn* __restrict__ pcm_in, const int64_t* __restrict__ in_off, const int32_t* __restrict__ in_len,
     int channels, const ResamplePlanHeader* __restrict__ plan, float* __restrict__ pcm_out,
     const int64_t* __restrict__ out_off, int32_t* __restrict__ out_len, unsigned* __restrict__ peak_keys,
-    int tiles_per_block) {
+    int tiles_per_block, int batch, int persistent) {
     using namespace rs;
     __shared__ __attribute__((aligned(16))) float rows[ORIG * kRowStride];
-    const int clip = blockIdx.y;
-    const int tid = threadIdx.x;
-    const int n = in_len[clip];
-    const int n_out = (n + ORIG - 1) / ORIG;                       // ceil(1 * n / ORIG)
-    if (blockIdx.x == 0 && tid == 0) out_len[clip] = n_out;
-    const int n_tiles = (n_out + kTile - 1) / kTile;
-    const int tile_begin = blockIdx.x * tiles_per_block;
-    const int tile_end = min(tile_begin + tiles_per_block, n_tiles);
-    if (tile_begin >= tile_end) return;
+    __shared__ int s_pref[kMaxPlanClips + 1];
+    __shared__ int s_wave_sum[kThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ h = reinterpret_cast<const float*>(plan + 1) + 2;      // taps of phase 0 (new_rate == 1 here)
+    const int width = plan->width;
+    auto tiles_of = [&](int n) { return ((n + ORIG - 1) / ORIG + kTile - 1) / kTile; };
+    auto runs_of = [&](int n) { return (tiles_of(n) + tiles_per_block - 1) / tiles_per_block; };
+
+    // Items are (clip, run of tiles_per_block tiles).  persistent: the grid is the resident workgroups, every one of
+    // them builds the exclusive prefix of the clips' run counts in LDS (items are clip-major over it, none is empty)
+    // and takes items blockIdx.x, blockIdx.x + gridDim.x, ...: lengths, offsets, the plan header, the taps and the
+    // first tile's round trip are paid once per workgroup instead of once per four tiles (with one item per workgroup
+    // 1 / 2 / 4 tiles per item took 0.47 / 0.25 / 0.185 ms on config 3: the start of a workgroup cost more than its
+    // tiles).  Otherwise (more than kMaxPlanClips clips): one item per workgroup, clip = blockIdx.y, run = blockIdx.x.
+    int n_items = 0, item = 0, item_step = 0;
+    if (persistent) {
+        constexpr int kPer = kMaxPlanClips / kThreads;
+        const int per = (batch + kThreads - 1) / kThreads;
+        int before[kPer], sum = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int c = tid * per + k;
+            before[k] = sum;
+            if (k < per && c < batch) {
+                const int n = in_len[c];
+                if (blockIdx.x == 0) out_len[c] = (n + ORIG - 1) / ORIG;        // ceil(1 * n / ORIG)
+                sum += runs_of(n);
+            }
+        }
+        int incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) s_wave_sum[wave] = incl;
+        __syncthreads();
+        int base = incl - sum;
+        for (int w = 0; w < wave; ++w) base += s_wave_sum[w];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int c = tid * per + k;
+            if (k < per && c < batch) s_pref[c] = base + before[k];
+        }
+        if (tid == kThreads - 1) s_pref[batch] = base + sum;
+        __syncthreads();
+        n_items = s_pref[batch];
+        item = blockIdx.x;
+        item_step = gridDim.x;
+        if (item >= n_items) return;
+    }
+    // item -> (clip, run): largest c with s_pref[c] <= it, two 64-way ballot steps (clips without samples have no run:
+    // the prefix repeats and the LAST clip of a repeat is the one that owns the item)
+    auto decode = [&](int it, int& clip_out, int& run_out) {
+        const int stride = (batch + 63) >> 6;
+        const int c1 = lane * stride;
+        const bool le1 = c1 < batch && s_pref[min(c1, batch)] <= it;
+        const int block = __popcll(__ballot(le1)) - 1;
+        const int c2 = block * stride + lane;
+        const bool le2 = lane < stride && c2 < batch && s_pref[min(c2, batch)] <= it;
+        const int c = block * stride + __popcll(__ballot(le2)) - 1;
+        clip_out = __builtin_amdgcn_readfirstlane(c);
+        run_out = __builtin_amdgcn_readfirstlane(it - s_pref[c]);
+    };
+    int clip, run;
+    if (persistent) {
+        decode(item, clip, run);
+    } else {
+        clip = blockIdx.y;
+        run = blockIdx.x;
+        if (run == 0 && tid == 0) out_len[clip] = (in_len[clip] + ORIG - 1) / ORIG;
+    }
+    int n = in_len[clip];
     const TIn* __restrict__ x = pcm_in + in_off[clip];
     float* __restrict__ y = pcm_out + out_off[clip];
-    const float* __restrict__ h = reinterpret_cast<const float*>(plan + 1) + 2 * plan->new_rate;   // taps of phase 0
-    const int width = plan->width;
-    float peak = 0.f;
+    if (!persistent && run * tiles_per_block >= tiles_of(n)) return;
 
     // padded[ORIG * o0 + g] = x[ORIG * o0 + g - width] (zero outside the clip) -> rows[g % ORIG][g / ORIG].
     // All loads of a tile are issued together (one HBM round trip per tile, not one per element: the compiler cannot
-    // move a load above an LDS store of the loop before it), and a tile ahead: the next tile's samples are requested
-    // right after this tile's have gone to LDS and arrive under its 168 FMAs per thread.
+    // move a load above an LDS store of the loop before it), and a tile ahead -- across items too: the next tile's
+    // samples are requested right after this tile's have gone to LDS and arrive under its 168 FMAs per thread.
     // int16 mono: one aligned 32-bit load brings two samples (single 2-byte loads ran at half the rate of the float
     // path).  Pairs are aligned in source-index space (clip starts are 4-byte aligned).
     constexpr bool kIs16 = sizeof(TIn) == 2;
-    const bool paired = kIs16 && channels == 1 && (reinterpret_cast<uintptr_t>(x) & 3) == 0;
     constexpr int kPairs = (ORIG * kRowLen + 2 + 1) / 2;
     constexpr int kPairsPerThread = (kPairs + kThreads - 1) / kThreads;
     constexpr int kPerThread = (ORIG * kRowLen + kThreads - 1) / kThreads;
     uint32_t stage2[kIs16 ? kPairsPerThread : 1];
     float stage[kPerThread];
-    auto request = [&](int tile) {
+    auto is_paired = [&](const TIn* xs) { return kIs16 && channels == 1 && (reinterpret_cast<uintptr_t>(xs) & 3) == 0; };
+    auto request = [&](const TIn* __restrict__ xs, int ns, int tile) {
         const int o0 = tile * kTile;
-        if (kIs16 && paired) {
+        if (kIs16 && is_paired(xs)) {
             const int base = ORIG * o0 - width;                     // source index of g = 0
             const int e_base = base & ~1;                           // even (floor also for negative base)
 #pragma unroll
             for (int i = 0; i < (kIs16 ? kPairsPerThread : 0); ++i) {
                 const int e = e_base + 2 * (tid + i * kThreads);
                 uint32_t w = 0;
-                if (e >= 0 && e + 1 < n) w = *reinterpret_cast<const uint32_t*>(x + e);
-                else if (e >= 0 && e < n) w = (uint16_t)x[e];
-                else if (e + 1 >= 0 && e + 1 < n) w = (uint32_t)(uint16_t)x[e + 1] << 16;
+                if (e >= 0 && e + 1 < ns) w = *reinterpret_cast<const uint32_t*>(xs + e);
+                else if (e >= 0 && e < ns) w = (uint16_t)xs[e];
+                else if (e + 1 >= 0 && e + 1 < ns) w = (uint32_t)(uint16_t)xs[e + 1] << 16;
                 stage2[i] = w;
             }
         } else {
@@ -116,12 +182,12 @@ __global__ __launch_bounds__(rs::kThreads) void decimate_peak_kernel(
             for (int i = 0; i < kPerThread; ++i) {
                 const int g = tid + i * kThreads;
                 const int src = ORIG * o0 + g - width;
-                stage[i] = (g < ORIG * kRowLen && src >= 0 && src < n) ? mono_at(x, n, channels, src) : 0.f;
+                stage[i] = (g < ORIG * kRowLen && src >= 0 && src < ns) ? mono_at(xs, ns, channels, src) : 0.f;
             }
         }
     };
-    auto deposit = [&](int tile) {
-        if (kIs16 && paired) {
+    auto deposit = [&](const TIn* xs, int tile) {
+        if (kIs16 && is_paired(xs)) {
             const int base = ORIG * tile * kTile - width;
             const int e_base = base & ~1;
 #pragma unroll
@@ -139,46 +205,101 @@ __global__ __launch_bounds__(rs::kThreads) void decimate_peak_kernel(
             }
         }
     };
-    request(tile_begin);
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
-        const int o0 = tile * kTile;
-        __syncthreads();                                            // previous tile's row reads are done
-        deposit(tile);
-        __syncthreads();
-        if (tile + 1 < tile_end) request(tile + 1);
-        float acc[kOutPerThread] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < ORIG; ++r) {
-            float v[20];
-            const f32x4* src = reinterpret_cast<const f32x4*>(rows + r * kRowStride + kOutPerThread * tid);
-#pragma unroll
-            for (int c = 0; c < 5; ++c) {
-                const f32x4 q = src[c];
-                v[4 * c] = q.x; v[4 * c + 1] = q.y; v[4 * c + 2] = q.z; v[4 * c + 3] = q.w;
+    // The item after the current one is held ready (clip, run, length, pointers: wave-uniform registers); the one
+    // after that is looked up at the top of every item and its length / offsets are requested with VECTOR loads (a
+    // lane offset the compiler cannot see through): scalar loads return out of order, so the first LDS read of the
+    // tile loop would wait for them (lgkmcnt(0)) -- 4 us per item on config 3 -- whereas vector loads are waited for
+    // in order, behind the tile's own samples, and have long arrived when the item becomes the next one.
+    int lane_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+    int clip_nx = clip, run_nx = 0, n_nx = 0;
+    const TIn* __restrict__ x_nx = x;
+    float* __restrict__ y_nx = y;
+    bool has_next = persistent && item + item_step < n_items;
+    if (has_next) {
+        decode(item + item_step, clip_nx, run_nx);
+        n_nx = in_len[clip_nx];
+        x_nx = pcm_in + in_off[clip_nx];
+        y_nx = pcm_out + out_off[clip_nx];
+    }
+    request(x, n, run * tiles_per_block);
+    while (true) {
+        const int n_out = (n + ORIG - 1) / ORIG;
+        const int tile_begin = run * tiles_per_block;
+        const int tile_end = min(tile_begin + tiles_per_block, tiles_of(n));
+        const int after_item = item + 2 * item_step;
+        const bool has_after = has_next && after_item < n_items;
+        int clip_nn = 0, run_nn = 0, v_n = 0;
+        int64_t v_in = 0, v_out = 0;
+        if (has_after) {
+            decode(after_item, clip_nn, run_nn);
+            v_n = in_len[clip_nn + lane_zero];
+            v_in = in_off[clip_nn + lane_zero];
+            v_out = out_off[clip_nn + lane_zero];
+        }
+        float peak = 0.f;
+        for (int tile = tile_begin; tile < tile_end; ++tile) {
+            const int o0 = tile * kTile;
+            __syncthreads();                                        // previous tile's row reads are done
+            deposit(x, tile);
+            __syncthreads();
+            {
+                const bool same = tile + 1 < tile_end;
+                if (same || has_next) request(same ? x : x_nx, same ? n : n_nx, same ? tile + 1 : run_nx * tiles_per_block);
             }
+            float acc[kOutPerThread] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < kTapsPerPhase; ++j) {
-                const float hj = h[ORIG * j + r];                   // wave-uniform (scalar load)
+            for (int r = 0; r < ORIG; ++r) {
+                float v[20];
+                const f32x4* src = reinterpret_cast<const f32x4*>(rows + r * kRowStride + kOutPerThread * tid);
 #pragma unroll
-                for (int q = 0; q < kOutPerThread; ++q) acc[q] = fmaf(hj, v[q + j], acc[q]);
+                for (int c = 0; c < 5; ++c) {
+                    const f32x4 q = src[c];
+                    v[4 * c] = q.x; v[4 * c + 1] = q.y; v[4 * c + 2] = q.z; v[4 * c + 3] = q.w;
+                }
+#pragma unroll
+                for (int j = 0; j < kTapsPerPhase; ++j) {
+                    const float hj = h[ORIG * j + r];               // wave-uniform (scalar load)
+#pragma unroll
+                    for (int q = 0; q < kOutPerThread; ++q) acc[q] = fmaf(hj, v[q + j], acc[q]);
+                }
+            }
+            const int o = o0 + kOutPerThread * tid;
+            if (o + kOutPerThread <= n_out && ((reinterpret_cast<uintptr_t>(y + o) & 15) == 0)) {
+                *reinterpret_cast<f32x4*>(y + o) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+#pragma unroll
+                for (int q = 0; q < kOutPerThread; ++q) peak = fmaxf(peak, fabsf(acc[q]));
+            } else {
+#pragma unroll
+                for (int q = 0; q < kOutPerThread; ++q)
+                    if (o + q < n_out) {
+                        y[o + q] = acc[q];
+                        peak = fmaxf(peak, fabsf(acc[q]));
+                    }
             }
         }
-        const int o = o0 + kOutPerThread * tid;
-        if (o + kOutPerThread <= n_out && ((reinterpret_cast<uintptr_t>(y + o) & 15) == 0)) {
-            *reinterpret_cast<f32x4*>(y + o) = f32x4{acc[0], acc[1], acc[2], acc[3]};
-#pragma unroll
-            for (int q = 0; q < kOutPerThread; ++q) peak = fmaxf(peak, fabsf(acc[q]));
-        } else {
-#pragma unroll
-            for (int q = 0; q < kOutPerThread; ++q)
-                if (o + q < n_out) {
-                    y[o + q] = acc[q];
-                    peak = fmaxf(peak, fabsf(acc[q]));
-                }
+        peak = wave_max(peak);
+        if (lane == 0 && peak > 0.f) atomicMax(&peak_keys[clip], __float_as_uint(peak));    // peak >= 0: bit order == value order
+        if (!has_next) break;
+        item += item_step;
+        clip = clip_nx;
+        run = run_nx;
+        n = n_nx;
+        x = x_nx;
+        y = y_nx;
+        has_next = has_after;
+        if (has_after) {
+            clip_nx = clip_nn;
+            run_nx = run_nn;
+            n_nx = __builtin_amdgcn_readfirstlane(v_n);
+            const int64_t io = ((int64_t)__builtin_amdgcn_readfirstlane((int)(v_in >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)v_in);
+            const int64_t oo = ((int64_t)__builtin_amdgcn_readfirstlane((int)(v_out >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)v_out);
+            x_nx = pcm_in + io;
+            y_nx = pcm_out + oo;
         }
     }
-    peak = wave_max(peak);
-    if ((tid & 63) == 0) atomicMax(&peak_keys[clip], __float_as_uint(peak));    // peak >= 0: bit order == value order
 }
 
 template <typename TIn>
@@ -315,6 +436,21 @@ extern "C" int sttfe_preprocess_workspace_bytes(int batch, size_t* bytes) {
     return STTFE_OK;
 }
 
+namespace sttfe { int current_device_cus(); }
+
+// Workgroups of the decimator that one CU holds (its registers and LDS decide), looked up once per instantiation.
+template <int O, typename TIn>
+static int decimate_resident_per_cu() {
+    static const int v = [] {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, decimate_peak_kernel<O, TIn>, rs::kThreads, 0) != hipSuccess ||
+            nb < 1)
+            nb = 4;
+        return nb;
+    }();
+    return v;
+}
+
 template <typename TIn>
 static int resample_peak_impl(const TIn* pcm_in, const int64_t* in_offsets, const int32_t* in_lengths,
                               int batch, int channels, int64_t max_in_length,
@@ -349,14 +485,26 @@ static int resample_peak_impl(const TIn* pcm_in, const int64_t* in_offsets, cons
         const bool fast = hp->new_rate == 1 && hp->taps_row <= rs::kTapsPerPhase * hp->orig_rate &&
                           (hp->orig_rate == 2 || hp->orig_rate == 3 || hp->orig_rate == 4 || hp->orig_rate == 6);
         if (fast) {
-            const int tiles_per_block = 4;
+            static const int tpb_env = getenv("STTFE_DECIMATE_TPB") ? atoi(getenv("STTFE_DECIMATE_TPB")) : 0;   // tuning knobs
+            static const int persist_env = getenv("STTFE_DECIMATE_PERSIST") ? atoi(getenv("STTFE_DECIMATE_PERSIST")) : 1;
+            const int tiles_per_block = tpb_env > 0 ? tpb_env : 8;     // 4 / 6 / 8 / 12 / 16: 0.188 / 0.179 / 0.177 / 0.183 / 0.186 ms (config 3)
             const int64_t n_tiles = (max_out + rs::kTile - 1) / rs::kTile;
             int bx = (int)((n_tiles + tiles_per_block - 1) / tiles_per_block);
             bx = bx < 1 ? 1 : bx;
-            const dim3 grid(bx, batch), block(rs::kThreads);
-#define STTFE_LAUNCH_DECIMATE(O)                                                                             \
-    hipLaunchKernelGGL((decimate_peak_kernel<O, TIn>), grid, block, 0, stream, pcm_in, in_offsets, in_lengths,      \
-                       channels, dp, pcm_out, out_offsets, out_lengths, keys, tiles_per_block)
+            const bool persistent = persist_env != 0 && batch <= rs::kMaxPlanClips;
+            const dim3 block(rs::kThreads);
+#define STTFE_LAUNCH_DECIMATE(O)                                                                                   \
+    {                                                                                                               \
+        dim3 grid(bx, batch);                                                                                       \
+        if (persistent) {                                                                                           \
+            const long resident = (long)decimate_resident_per_cu<O, TIn>() * current_device_cus();                  \
+            const long most = (long)bx * batch;                                                                     \
+            grid = dim3((unsigned)(most < resident ? most : resident));                                             \
+        }                                                                                                           \
+        hipLaunchKernelGGL((decimate_peak_kernel<O, TIn>), grid, block, 0, stream, pcm_in, in_offsets, in_lengths,  \
+                           channels, dp, pcm_out, out_offsets, out_lengths, keys, tiles_per_block, batch,           \
+                           persistent ? 1 : 0);                                                                     \
+    }
             switch (hp->orig_rate) {
                 case 2: STTFE_LAUNCH_DECIMATE(2); break;
                 case 3: STTFE_LAUNCH_DECIMATE(3); break;

@@ -104,3 +104,33 @@ def test_resample_then_whisper_config3_shape():
     exp = whisper_features([R.preprocess(c[None, :], 48000, trim_silence=False, min_duration=0.0, max_duration=1e9)["audio"]
                             for c in clips], 80)
     assert np.abs(got - exp).max() <= 1e-4
+
+
+def test_decimator_item_boundaries_and_both_launch_forms():
+    """The 48 -> 16 kHz decimator walks (clip, run of 8 tiles of 1024 outputs) items with persistent workgroups for up to
+    2048 clips and one item per workgroup beyond that: clip lengths on and around tile / item boundaries against the
+    oracle, and a 2100-clip batch (second form) bit-identical to the same clips in batches of 700 (first form)."""
+    from speech_to_text_amd.preprocess import GpuAudioPreprocessor
+    pre = GpuAudioPreprocessor(normalize=False, trim_silence=False, min_duration=0.0, max_duration=1e9, device=DEV)
+    sr, item = 48000, 3 * 1024 * 8
+    lens = [item, item + 1, item - 1, 2 * item + 3 * 1024, 3 * 1024, 3 * 1024 + 2, 17 * 3 * 1024 + 7, 5, 3 * item - 2]
+    clips = [make(sr, n, 300 + i) for i, n in enumerate(lens)]
+    p = pre.preprocess_batch(clips, sr)
+    peaks = pre.last_peaks.cpu().numpy()
+    for i, c in enumerate(clips):
+        exp = R.resample(c, sr, 16000)
+        got = p.clip(i)[0].cpu().numpy()
+        assert got.shape == exp.shape and np.abs(got - exp).max() <= 2e-6, (lens[i], float(np.abs(got - exp).max()))
+        assert peaks[i] == np.abs(got).max()
+    rng = np.random.default_rng(9)
+    many = [make(sr, int(n), 1000 + i) for i, n in enumerate(rng.integers(1, 9000, size=2100))]
+    big = pre.preprocess_batch(many, sr)
+    big_peaks = pre.last_peaks.cpu().numpy()
+    for c0 in range(0, 2100, 700):
+        part = pre.preprocess_batch(many[c0:c0 + 700], sr)
+        part_peaks = pre.last_peaks.cpu().numpy()
+        for i in range(700):
+            assert torch.equal(big.clip(c0 + i)[0], part.clip(i)[0]), c0 + i
+        assert np.array_equal(big_peaks[c0:c0 + 700], part_peaks)
+    for i in (0, 699, 2099):
+        assert np.abs(big.clip(i)[0].cpu().numpy() - R.resample(many[i], sr, 16000)).max() <= 2e-6
