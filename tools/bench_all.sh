@@ -26,3 +26,4 @@ run resample_whisper_fused --workload resample_whisper --steps 20 --warmup 5 --n
 run resample_whisper_s16 --workload resample_whisper_s16 --steps 20 --warmup 5 --no-cpu-baseline
 run whisper128_aug --workload whisper128_aug --steps 20 --warmup 5 --no-cpu-baseline
 run corpus --workload corpus --steps 5 --warmup 2 --no-cpu-baseline
+run corpus_compact --workload corpus_compact --steps 5 --warmup 2 --no-cpu-baseline
