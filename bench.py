@@ -210,6 +210,8 @@ def main():
     ap.add_argument("--fused-normalize", action="store_true",
                     help="resample_whisper workloads: peak normalisation folded into the Whisper kernel "
                          "(sttfe_whisper_logmel_scaled) instead of a pass of its own")
+    ap.add_argument("--trim-silence", action="store_true",
+                    help="resample_whisper workloads: silence trimming on (SURVEY.md 8d: config 3's second line)")
     ap.add_argument("--event-stride", type=int, default=2,
                     help="HIP events bracket every n-th launch of each kernel in the timed region (2: ten timed launches "
                          "at --steps 20): an event pair drains the queue around its launch (a headline step takes 1.035 ms "
@@ -366,7 +368,7 @@ def main():
             table = sampler.mask_table([(n_mels, 3000)] * B).to(device)      # drawn once: RNG is host work
             step = lambda slot=0: fe.extract(pcm, offsets, lengths, mask_table=table, out=outs[slot])
         else:
-            pre = GpuAudioPreprocessor(normalize=True, trim_silence=False, min_duration=0.0, max_duration=1e9,
+            pre = GpuAudioPreprocessor(normalize=True, trim_silence=args.trim_silence, min_duration=0.0, max_duration=1e9,
                                        device=device)
             extra_kernels = ["resample_peak", "normalize_trim"]
 
@@ -375,11 +377,11 @@ def main():
                 extra_kernels = ["resample_peak"]
 
                 def step(slot=0):
-                    p = pre.run(pcm, offsets, lengths, host_lens, 1, 48000, defer_normalize=True)
+                    p = pre.run(pcm, offsets, lengths, host_lens, 1, 48000, defer_normalize=True, sync_lengths=False)
                     fe.extract(p.pcm, p.offsets, p.lengths, out=outs[slot], clip_scale=p.scale)
             else:
                 def step(slot=0):
-                    p = pre.run(pcm, offsets, lengths, host_lens, 1, 48000)
+                    p = pre.run(pcm, offsets, lengths, host_lens, 1, 48000, sync_lengths=False)   # no duration gate: no D2H
                     fe.extract(p.pcm, p.offsets, p.lengths, out=outs[slot])
     else:
         fe = HipSpeech2TextFeatureExtractor(device=device, stft_precision="float32" if s2t_f32 else "float64")
@@ -514,7 +516,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": shapes[wl] + (" (int16 decoded PCM)" if s16 else "")
                                    + ((" (float32 STFT mode)" if s2t_f32 else " (float64 STFT + NumPy-order CMVN: HF NumPy-path parity mode)") if wl == "s2t" else "")
-                                   + (" (normalisation fused into the feature kernel)" if args.fused_normalize and wl == "resample_whisper" else ""), "clips_per_gpu": B, "n_mels": n_mels,
+                                   + (" (normalisation fused into the feature kernel)" if args.fused_normalize and wl == "resample_whisper" else "")
+                                   + (" (silence trimming on)" if args.trim_silence and wl == "resample_whisper" else ""), "clips_per_gpu": B, "n_mels": n_mels,
                        "sharding": f"clip-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
