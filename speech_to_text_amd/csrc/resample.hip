@@ -79,6 +79,7 @@ __global__ __launch_bounds__(rs::kThreads) void decimate_peak_kernel(
     __shared__ __attribute__((aligned(16))) float rows[ORIG * kRowStride];
     __shared__ int s_pref[kMaxPlanClips + 1];
     __shared__ int s_wave_sum[kThreads / 64];
+    __shared__ float s_peak[kThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* __restrict__ h = reinterpret_cast<const float*>(plan + 1) + 2;      // taps of phase 0 (new_rate == 1 here)
     const int width = plan->width;
@@ -282,8 +283,16 @@ __global__ __launch_bounds__(rs::kThreads) void decimate_peak_kernel(
                     }
             }
         }
+        // one atomic per workgroup and item (items are clip-major: some 40 workgroups work on a clip at a time, and
+        // device-scope read-modify-writes on one word queue behind each other)
         peak = wave_max(peak);
-        if (lane == 0 && peak > 0.f) atomicMax(&peak_keys[clip], __float_as_uint(peak));    // peak >= 0: bit order == value order
+        if (lane == 0) s_peak[wave] = peak;
+        __syncthreads();
+        if (tid == 0) {
+            float m = s_peak[0];
+            for (int w = 1; w < kThreads / 64; ++w) m = fmaxf(m, s_peak[w]);
+            if (m > 0.f) atomicMax(&peak_keys[clip], __float_as_uint(m));                   // peak >= 0: bit order == value order
+        }
         if (!has_next) break;
         item += item_step;
         clip = clip_nx;
