@@ -183,7 +183,8 @@ int sttfe_resample_plan_info(const void* host_blob, int* orig_rate, int* new_rat
 /* ceil(new * n_in / orig): the output length torchaudio crops to. */
 int sttfe_resample_out_length(int orig_sr, int new_sr, int64_t n_in, int64_t* n_out);
 
-/* Device workspace shared by the two calls below: per-clip peak keys + trim bounds. */
+/* Device workspace shared by the two calls below: per-clip peak keys + 64 + 64 candidate slots per clip for the trim
+ * bounds (516 bytes per clip). */
 int sttfe_preprocess_workspace_bytes(int batch, size_t* bytes);
 
 /*
