@@ -166,11 +166,42 @@ __global__ __launch_bounds__(rs::kThreads) void decimate_peak_kernel(
     constexpr int kPairsPerThread = (kPairs + kThreads - 1) / kThreads;
     constexpr int kPerThread = (ORIG * kRowLen + kThreads - 1) / kThreads;
     uint32_t stage2[kIs16 ? kPairsPerThread : 1];
+    uint32_t stage_left = 0;
     float stage[kPerThread];
     auto is_paired = [&](const TIn* xs) { return kIs16 && channels == 1 && (reinterpret_cast<uintptr_t>(xs) & 3) == 0; };
+    // int16, whole span (and a sample either side) inside the clip: thread u takes the 4 ORIG consecutive samples
+    // g = 4 ORIG u .., i.e. elements 4u .. 4u + 3 of every phase row, as 2 ORIG + 1 aligned 32-bit words (the span
+    // starts on an odd sample in every other tile: the words are then shifted by 16 bits, wave-uniformly), and the
+    // 16 ORIG samples behind the 256 chunks go one each to the first threads.  No g / ORIG, g % ORIG, no bounds and
+    // ORIG 16-byte LDS writes per thread instead of 8 ORIG + 2 scalar ones: the staging arithmetic was what bound
+    // the int16 path.
+    constexpr int kChunk = 4 * ORIG;
+    constexpr int kWords = kChunk / 2 + 1;
+    constexpr int kLeft = ORIG * kRowLen - kChunk * kThreads;
+    static_assert(!kIs16 || (kWords <= kPairsPerThread && kLeft >= 0 && kLeft <= kThreads), "vector staging fits the pair stage");
+    auto interior16 = [&](const TIn* xs, int ns, int tile) {
+        const int first = ORIG * tile * kTile - width;
+        return kIs16 && is_paired(xs) && first >= 1 && first + ORIG * kRowLen + 1 <= ns;
+    };
+    struct u32x4a4 { uint32_t v[4]; } __attribute__((packed, aligned(4)));
     auto request = [&](const TIn* __restrict__ xs, int ns, int tile) {
         const int o0 = tile * kTile;
-        if (kIs16 && is_paired(xs)) {
+        if (kIs16 && interior16(xs, ns, tile)) {
+            const int first = ORIG * o0 - width;
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(xs + ((first + kChunk * tid) & ~1));
+#pragma unroll
+            for (int i = 0; i < (kIs16 ? kWords : 0); i += 4) {
+                if (i + 4 <= kWords) {
+                    u32x4a4 q;
+                    __builtin_memcpy(&q, src + i, sizeof(q));
+                    stage2[i] = q.v[0]; stage2[i + 1] = q.v[1]; stage2[i + 2] = q.v[2]; stage2[i + 3] = q.v[3];
+                } else {
+#pragma unroll
+                    for (int k = i; k < kWords; ++k) stage2[k] = src[k];
+                }
+            }
+            if (tid < kLeft) stage_left = (uint16_t)xs[first + kChunk * kThreads + tid];
+        } else if (kIs16 && is_paired(xs)) {
             const int base = ORIG * o0 - width;                     // source index of g = 0
             const int e_base = base & ~1;                           // even (floor also for negative base)
 #pragma unroll
@@ -191,8 +222,21 @@ __global__ __launch_bounds__(rs::kThreads) void decimate_peak_kernel(
             }
         }
     };
-    auto deposit = [&](const TIn* xs, int tile) {
-        if (kIs16 && is_paired(xs)) {
+    auto deposit = [&](const TIn* xs, int ns, int tile) {
+        if (kIs16 && interior16(xs, ns, tile)) {
+            const bool odd = (ORIG * tile * kTile - width) & 1;      // wave-uniform
+            float f[kChunk];
+#pragma unroll
+            for (int i = 0; i < (kIs16 ? kChunk / 2 : 0); ++i) {
+                const uint32_t w = odd ? __builtin_amdgcn_alignbit(stage2[i + 1], stage2[i], 16) : stage2[i];
+                f[2 * i] = to_f32((int16_t)(w & 0xffffu));
+                f[2 * i + 1] = to_f32((int16_t)(w >> 16));
+            }
+#pragma unroll
+            for (int r = 0; r < ORIG; ++r)                          // sample q of the chunk: row q % ORIG, element 4u + q / ORIG
+                *reinterpret_cast<f32x4*>(rows + r * kRowStride + 4 * tid) = f32x4{f[r], f[r + ORIG], f[r + 2 * ORIG], f[r + 3 * ORIG]};
+            if (tid < kLeft) rows[(tid % ORIG) * kRowStride + 4 * kThreads + tid / ORIG] = to_f32((int16_t)stage_left);
+        } else if (kIs16 && is_paired(xs)) {
             const int base = ORIG * tile * kTile - width;
             const int e_base = base & ~1;
 #pragma unroll
@@ -246,7 +290,7 @@ __global__ __launch_bounds__(rs::kThreads) void decimate_peak_kernel(
         for (int tile = tile_begin; tile < tile_end; ++tile) {
             const int o0 = tile * kTile;
             __syncthreads();                                        // previous tile's row reads are done
-            deposit(x, tile);
+            deposit(x, n, tile);
             __syncthreads();
             {
                 const bool same = tile + 1 < tile_end;
