@@ -48,6 +48,22 @@ static_assert(kRowStride >= kRowLen && kRowStride % 4 == 0, "phase row stride");
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef STTFE_STAMPS
+// Diagnostic build only (tools/stamps_decimate.py): per-wave cycle sums of the phases of the decimator's tile loop.
+__device__ unsigned long long* g_rs_stamp_buf = nullptr;
+#define RS_STAMP(i)                                                              \
+    do {                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        unsigned long long t_;                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        stamp_sum[i] += t_ - stamp_prev;                                         \
+        stamp_prev = t_;                                                         \
+    } while (0)
+#else
+#define RS_STAMP(i)
+#endif
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
@@ -81,6 +97,11 @@ __global__ __launch_bounds__(rs::kThreads) void decimate_peak_kernel(
     __shared__ int s_wave_sum[kThreads / 64];
     __shared__ float s_peak[kThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef STTFE_STAMPS
+    unsigned long long stamp_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+    const unsigned long long stamp_entry = stamp_prev;
+#endif
     const float* __restrict__ h = reinterpret_cast<const float*>(plan + 1) + 2;      // taps of phase 0 (new_rate == 1 here)
     const int width = plan->width;
     auto tiles_of = [&](int n) { return ((n + ORIG - 1) / ORIG + kTile - 1) / kTile; };
@@ -272,6 +293,7 @@ __global__ __launch_bounds__(rs::kThreads) void decimate_peak_kernel(
         y_nx = pcm_out + out_off[clip_nx];
     }
     request(x, n, run * tiles_per_block);
+    RS_STAMP(7);
     while (true) {
         const int n_out = (n + ORIG - 1) / ORIG;
         const int tile_begin = run * tiles_per_block;
@@ -289,13 +311,22 @@ __global__ __launch_bounds__(rs::kThreads) void decimate_peak_kernel(
         float peak = 0.f;
         for (int tile = tile_begin; tile < tile_end; ++tile) {
             const int o0 = tile * kTile;
+            RS_STAMP(6);
             __syncthreads();                                        // previous tile's row reads are done
+            RS_STAMP(5);
+#ifdef STTFE_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            RS_STAMP(8);
+#endif
             deposit(x, n, tile);
+            RS_STAMP(0);
             __syncthreads();
+            RS_STAMP(1);
             {
                 const bool same = tile + 1 < tile_end;
                 if (same || has_next) request(same ? x : x_nx, same ? n : n_nx, same ? tile + 1 : run_nx * tiles_per_block);
             }
+            RS_STAMP(2);
             float acc[kOutPerThread] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < ORIG; ++r) {
@@ -313,6 +344,7 @@ __global__ __launch_bounds__(rs::kThreads) void decimate_peak_kernel(
                     for (int q = 0; q < kOutPerThread; ++q) acc[q] = fmaf(hj, v[q + j], acc[q]);
                 }
             }
+            RS_STAMP(3);
             const int o = o0 + kOutPerThread * tid;
             if (o + kOutPerThread <= n_out && ((reinterpret_cast<uintptr_t>(y + o) & 15) == 0)) {
                 *reinterpret_cast<f32x4*>(y + o) = f32x4{acc[0], acc[1], acc[2], acc[3]};
@@ -327,6 +359,7 @@ __global__ __launch_bounds__(rs::kThreads) void decimate_peak_kernel(
                     }
             }
         }
+        RS_STAMP(4);
         // one atomic per workgroup and item (items are clip-major: some 40 workgroups work on a clip at a time, and
         // device-scope read-modify-writes on one word queue behind each other)
         peak = wave_max(peak);
@@ -357,6 +390,14 @@ __global__ __launch_bounds__(rs::kThreads) void decimate_peak_kernel(
             y_nx = pcm_out + oo;
         }
     }
+#ifdef STTFE_STAMPS
+    if (g_rs_stamp_buf && lane == 0 && persistent) {
+        RS_STAMP(6);
+        stamp_sum[9] = stamp_prev - stamp_entry;
+        unsigned long long* dst = g_rs_stamp_buf + ((size_t)blockIdx.x * (kThreads / 64) + wave) * 10;
+        for (int i = 0; i < 10; ++i) dst[i] = stamp_sum[i];
+    }
+#endif
 }
 
 template <typename TIn>
@@ -510,6 +551,13 @@ __global__ __launch_bounds__(256) void trim_finalize_kernel(int64_t* __restrict_
 }  // namespace sttfe
 
 using namespace sttfe;
+
+#ifdef STTFE_STAMPS
+extern "C" int sttfe_debug_set_rs_stamp_buffer(void* dev_buf) {
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(dev_buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_rs_stamp_buf), &p, sizeof(p)) == hipSuccess ? 0 : -4;
+}
+#endif
 
 // workspace layout: [peak keys u32 x B][first i32 x B x kTrimSlots][last i32 x B x kTrimSlots], 256-byte aligned total
 extern "C" int sttfe_preprocess_workspace_bytes(int batch, size_t* bytes) {

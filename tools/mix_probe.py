@@ -2,7 +2,8 @@
 plus a 1 : 1 copy and a read-only pass of the same bytes for comparison."""
 import time
 import torch
-n = 60_000_000
+import sys
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60_000_000      # 60 M: config 3's sizes (partly served by the 256 MB Infinity Cache when looped)
 x = torch.randn(2 * n, dtype=torch.float32, device="cuda")
 y = torch.empty(n, dtype=torch.float32, device="cuda")
 z = torch.empty(2 * n, dtype=torch.float32, device="cuda")
