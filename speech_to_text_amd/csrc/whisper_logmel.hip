@@ -190,7 +190,7 @@ __device__ __forceinline__ bool plan_matches(const MelPlan& p) {
 //            the plain stores after one scalar test, the others write 0.0 over the masked cells
 template <int NM, int MT, bool kMask>
 __device__ __forceinline__ void mel_unit_static(const float* __restrict__ a_lane, const float* __restrict__ b_lane,
-                                           float* __restrict__ out_u, const unsigned (&o_r)[4], float mel_floor,
+                                           float* __restrict__ out_u, unsigned (&o_r)[4], float mel_floor,
                                            float y_bias, float& run_max, float& tile_min, unsigned tbits, unsigned mbits,
                                            int lane) {
     using P = wh::StaticPlan<NM>;
@@ -213,14 +213,17 @@ __device__ __forceinline__ void mel_unit_static(const float* __restrict__ a_lane
         mv[r] = fmaxf(acc[r], mel_floor);
         yv[r] = fmaf(__log2f(mv[r]), 0.25f * 0.30102999566398120f, y_bias);
     }
+#pragma unroll                                                        // opaque in place: the zero-extension then stays beside
+    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(o_r[r]));      // the store, which takes scalar base + 32-bit lane offset
     if (kMask && (tbits | mbits) != 0u) {                             // wave-uniform
         const bool tmasked = (tbits >> (lane & 15)) & 1u;
         const unsigned mb = (mbits >> ((lane >> 4) * 4)) & 15u;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out_u[o_r[r]] = (tmasked || ((mb >> r) & 1u)) ? 0.0f : yv[r];
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(out_u) + o_r[r]) = (tmasked || ((mb >> r) & 1u)) ? 0.0f : yv[r];
     } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out_u[o_r[r]] = yv[r];
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(reinterpret_cast<char*>(out_u) + o_r[r]) = yv[r];
     }
     // max / min count the masked cells too: the masks are applied to the finished features (src/data.py:185-194)
     run_max = fmaxf(fmaxf(run_max, fmaxf(mv[0], mv[1])), fmaxf(mv[2], mv[3]));
@@ -604,7 +607,8 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     const float* a_lane = smem + kAfragOff + 4 * lane;
     unsigned o_r[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o_r[r] = (unsigned)(((lane >> 4) * 4 + r) * n_frames + (lane & 15));
+    for (int r = 0; r < 4; ++r) o_r[r] = 4u * (unsigned)(((lane >> 4) * 4 + r) * n_frames + (lane & 15));   // BYTES: a 32-bit
+    // lane offset beside the unit's scalar base is the store's own addressing mode (no 64-bit add per store)
 #ifdef STTFE_STAMPS
     // slots 0-9: phases of the tile loop; 10: kernel entry -> item loop; 11: item switches (end of an item's last tile
     // -> start of the next item's first tile, empty items included); 12: after the last item; 13 / 14: entry / exit time;
