@@ -134,3 +134,32 @@ def test_decimator_item_boundaries_and_both_launch_forms():
         assert np.array_equal(big_peaks[c0:c0 + 700], part_peaks)
     for i in (0, 699, 2099):
         assert np.abs(big.clip(i)[0].cpu().numpy() - R.resample(many[i], sr, 16000)).max() <= 2e-6
+
+
+def test_decimator_empty_clips_between_others():
+    """Clips without samples have no item in the decimator's prefix (it repeats there): their neighbours' items must
+    still resolve to the right clip, their output length is 0 and their peak key stays 0."""
+    from speech_to_text_amd.preprocess import GpuAudioPreprocessor
+    pre = GpuAudioPreprocessor(normalize=False, trim_silence=False, min_duration=0.0, max_duration=1e9, device=DEV)
+    sr = 48000
+    lens = [0, 5000, 0, 0, 3 * 1024 * 8 + 5, 0, 1, 0, 70001, 0]
+    n_max = 70016
+    host = np.zeros((len(lens), n_max), np.float32)
+    for i, n in enumerate(lens):
+        if n:
+            host[i, :n] = make(sr, n, 500 + i)
+    pcm = torch.from_numpy(host).to(DEV).reshape(-1)
+    off = (torch.arange(len(lens), dtype=torch.int64) * n_max).to(DEV)
+    ln = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    p = pre.run(pcm, off, ln, lens, 1, sr, sync_lengths=False)
+    assert p.lengths.cpu().tolist() == [(n + 2) // 3 for n in lens]
+    peaks = pre.last_peaks.cpu().numpy()
+    for i, n in enumerate(lens):
+        if n == 0:
+            assert peaks[i] == 0.0
+            continue
+        exp = R.resample(host[i, :n], sr, 16000)
+        o = int(p.offsets[i].item())
+        got = p.pcm[o:o + exp.shape[0]].cpu().numpy()
+        assert np.abs(got - exp).max() <= 2e-6, (i, n)
+        assert peaks[i] == np.abs(got).max()
