@@ -38,13 +38,10 @@ constexpr int kTile = kThreads * kOutPerThread;       // 1024 outputs per tile
 constexpr int kTapsPerPhase = 14;                     // ceil((2 width + ORIG) / ORIG) for every ORIG:1 ratio
 constexpr int kRowLen = kTile + 16;                   // m range a tile reads: 4 * 255 + 20
 constexpr int kRowStride = 1068;                      // words; % 4 == 0 (b128 alignment), % 32 == 12
-constexpr int kTrimSlots = 64;                        // per-clip candidate slots of the trim bounds (normalize_trim_kernel)
-}  // namespace rs
-constexpr int kTrimSlots = rs::kTrimSlots;
-namespace rs {
 constexpr int kMaxPlanClips = 2048;                   // clips whose run-count prefix a persistent workgroup keeps in LDS
 static_assert(kRowStride >= kRowLen && kRowStride % 4 == 0, "phase row stride");
 }  // namespace rs
+constexpr int kTrimSlots = 64;                        // per-clip candidate slots of the trim bounds (normalize_trim_kernel)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
