@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void resample_generic_lds_kernel(
     const TIn* __restrict__ pcm_in, const int64_t* __restrict__ in_off, const int32_t* __restrict__ in_len,
     int channels, const ResamplePlanHeader* __restrict__ plan, float* __restrict__ pcm_out,
     const int64_t* __restrict__ out_off, int32_t* __restrict__ out_len, unsigned* __restrict__ peak_keys,
-    int blocks, int lmax, int tiles_per_wg) {
+    int blocks, int lmax, int tiles_per_wg, int via_lds) {
     extern __shared__ __attribute__((aligned(16))) float g_smem[];
     const int clip = blockIdx.y, tid = threadIdx.x;
     const int n = in_len[clip];
@@ -468,6 +468,7 @@ __global__ __launch_bounds__(256) void resample_generic_lds_kernel(
     float* taps_c = g_smem;                                            // [nw][lmax]
     int* lo_s = reinterpret_cast<int*>(g_smem + nw * lmax);            // [nw]
     float* xs = reinterpret_cast<float*>(lo_s + nw);                   // [blocks * orig + 2 width + lmax]
+    float* out_s = xs + blocks * orig + 2 * width + lmax;              // [blocks * nw] (via_lds only)
     for (int p = tid; p < nw; p += 256) lo_s[p] = lo[p];
     for (int e = tid; e < nw * lmax; e += 256) {                       // rows zero-filled behind the phase's own span
         const int p = e / lmax, j = e - p * lmax;
@@ -489,8 +490,7 @@ __global__ __launch_bounds__(256) void resample_generic_lds_kernel(
         __syncthreads();
         const int o_base = tile * blocks * nw;
         const int n_here = min(blocks * nw, n_out - o_base);
-        for (int e = tid; e < n_here; e += 256) {
-            const int il = e / nw, p = e - il * nw;
+        auto dot = [&](int il, int p) {
             const float* __restrict__ xp = xs + il * orig + lo_s[p];
             const float* __restrict__ tp = taps_c + p * lmax;
             float acc = 0.f;
@@ -506,8 +506,31 @@ __global__ __launch_bounds__(256) void resample_generic_lds_kernel(
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc = fmaf(t8[j], x8[j], acc);
             }
-            y[o_base + e] = acc;
-            peak = fmaxf(peak, fabsf(acc));
+            return acc;
+        };
+        if (via_lds) {
+            // odd orig >= 3 and tiles of >= 64 blocks: lanes take consecutive input blocks of ONE phase -- their sample reads are orig words apart
+            // (conflict-free for odd orig; with consecutive phases per lane they start ~orig / new words apart and
+            // collide about three ways) and the phase's taps are a broadcast; the outputs, new_rate apart for such
+            // lanes, go through an LDS tile and leave in output order
+            for (int e = tid; e < blocks * nw; e += 256) {
+                const int p = e / blocks, il = e - p * blocks;
+                const int ol = il * nw + p;
+                if (ol < n_here) out_s[ol] = dot(il, p);
+            }
+            __syncthreads();
+            for (int e = tid; e < n_here; e += 256) {
+                const float v = out_s[e];
+                y[o_base + e] = v;
+                peak = fmaxf(peak, fabsf(v));
+            }
+        } else {
+            for (int e = tid; e < n_here; e += 256) {
+                const int il = e / nw, p = e - il * nw;
+                const float acc = dot(il, p);
+                y[o_base + e] = acc;
+                peak = fmaxf(peak, fabsf(acc));
+            }
         }
     }
     __shared__ float s_peak[4];
@@ -777,17 +800,21 @@ static int resample_peak_impl(const TIn* pcm_in, const int64_t* in_offsets, cons
             // tap loop), large ones amortise the 2 width + lmax halo of the staged span
             const long target = tile_env > 0 ? tile_env : 1024;
             long blocks = (target + nw - 1) / nw;
-            if (fixed + blocks * orig > words) blocks = (words - fixed) / orig;
+            // phase-major lanes + an LDS output tile (see the kernel) pay when a wave stays inside one phase and the
+            // sample stride is odd and not 1: 3:2 0.33 -> 0.27 ms; 441:160 (7 blocks per tile) 0.67 -> 0.86 ms without this test
+            const bool via_lds = (orig & 1) && orig >= 3 && blocks >= 64 && fixed + blocks * (orig + nw) <= words;
+            const long per_block = orig + (via_lds ? nw : 0);
+            if (fixed + blocks * per_block > words) blocks = (words - fixed) / per_block;
             if (!lds_off && fixed < words && blocks >= 1) {
                 const long tile_out = blocks * nw;
                 const int tiles_per_wg = (int)(tile_out >= 32768 ? 1 : (32768 + tile_out - 1) / tile_out);
                 const int64_t n_tiles = ((max_out + nw - 1) / nw + blocks - 1) / blocks;
                 int bx = (int)((n_tiles + tiles_per_wg - 1) / tiles_per_wg);
                 bx = bx < 1 ? 1 : bx;
-                const size_t lds = (size_t)(fixed + blocks * orig) * 4;
+                const size_t lds = (size_t)(fixed + blocks * per_block) * 4;
                 hipLaunchKernelGGL(resample_generic_lds_kernel<TIn>, dim3(bx, batch), dim3(256), lds, stream, pcm_in,
                                    in_offsets, in_lengths, channels, dp, pcm_out, out_offsets, out_lengths, keys,
-                                   (int)blocks, lmax, tiles_per_wg);
+                                   (int)blocks, lmax, tiles_per_wg, via_lds ? 1 : 0);
             } else {
                 int bx = (int)((max_out + 256 * 4 - 1) / (256 * 4));
                 bx = bx < 1 ? 1 : (bx > 2048 ? 2048 : bx);
