@@ -25,7 +25,7 @@ def make(sr, n, seed, zero_edges=0):
     return x
 
 
-@pytest.mark.parametrize("sr", [48000, 32000, 44100, 96000, 8000])
+@pytest.mark.parametrize("sr", [48000, 32000, 44100, 96000, 8000, 24000, 22050, 11025])
 def test_resample_matches_oracle(sr):
     from speech_to_text_amd.preprocess import GpuAudioPreprocessor
     pre = GpuAudioPreprocessor(normalize=False, trim_silence=False, min_duration=0.0, max_duration=1e9, device=DEV)
