@@ -78,6 +78,8 @@ __device__ __forceinline__ float to_f32(int16_t v) { return (float)v * (1.0f / 3
 template <typename TIn>
 __device__ __forceinline__ float mono_at(const TIn* __restrict__ x, int n, int channels, int i) {
     if (channels == 1) return to_f32(x[i]);
+    if (channels == 2)      // stereo: two independent loads (the loop below waits for each load before the next)
+        return (0.f + to_f32(x[i]) + to_f32(x[(size_t)n + i])) / 2.0f;
     float s = 0.f;
     for (int c = 0; c < channels; ++c) s += to_f32(x[(size_t)c * n + i]);
     return s / (float)channels;
