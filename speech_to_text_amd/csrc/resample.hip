@@ -796,7 +796,7 @@ static int resample_peak_impl(const TIn* pcm_in, const int64_t* in_offsets, cons
             lmax = ((lmax + 7) & ~7) + 1;                               // taps in groups of 8; odd row stride: consecutive phases land in different banks
             static const bool lds_off = getenv("STTFE_RESAMPLE_GENERIC_GLOBAL") != nullptr;     // A/B and test knob
             static const int tile_env = getenv("STTFE_RESAMPLE_GENERIC_TILE") ? atoi(getenv("STTFE_RESAMPLE_GENERIC_TILE")) : 0;
-            const long words = 64 * 1024 / 4;
+            const long words = (64 * 1024 - 256) / 4;                   // 64 KB of LDS per workgroup, minus the kernel's static words
             const long fixed = (long)nw * lmax + nw + 2L * hp->width + lmax;
             // outputs per tile: small tiles keep the LDS footprint low (more workgroups per CU hide the LDS latency of the
             // tap loop), large ones amortise the 2 width + lmax halo of the staged span
