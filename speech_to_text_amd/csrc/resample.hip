@@ -14,8 +14,9 @@
 //   thread that owns 4 consecutive outputs reads each row with five conflict-free ds_read_b128
 //   (17 of 20 values used) instead of 41 scalar reads per output.  Taps are wave-uniform (SGPRs).
 //   Output: one global_store_dwordx4 per thread; per-clip max|out| with one atomicMax per wave.
-// Kernel 1b (resample_generic_lds): any ORIG:NEW ratio (44.1 / 22.05 / 8 kHz sources, speed perturbation): compact
-//   per-phase taps and the source span of a 1024-output tile in LDS, outputs in output order.  resample_generic
+// Kernel 1b (resample_generic_quad / resample_generic_lds): any ORIG:NEW ratio (44.1 / 22.05 / 8 kHz sources, speed
+//   perturbation): compact per-phase taps and the source span of a tile in LDS, the next tile's samples requested a
+//   tile ahead; four consecutive outputs per thread off one sample window when NEW % 4 == 0.  resample_generic
 //   (one thread per output, everything from global memory) remains for ratios whose taps do not fit 64 KB.
 // Kernel 1c (copy_peak): same-rate input: mono mix / copy / peak only.
 // Kernel 2 (normalize_trim): y = x / (peak + 1e-8) in place (IEEE division, bit-identical to the
@@ -482,14 +483,35 @@ __global__ __launch_bounds__(256) void resample_generic_lds_kernel(
     const int span = blocks * orig + 2 * width;
     for (int e = tid; e < lmax; e += 256) xs[span + e] = 0.f;          // the padded taps of the last block read zeros here
     float peak = 0.f;
+    // spans of up to 16 samples per thread are requested a tile ahead (registers): the HBM round trip of tile t + 1
+    // runs under the arithmetic of tile t; longer spans are staged in place
+    constexpr int kStage = 16;
+    const bool ahead = span <= kStage * 256;
+    float st[kStage];
+    auto request = [&](int tile) {
+        const int s0 = tile * blocks * orig - width;
+#pragma unroll
+        for (int i = 0; i < kStage; ++i) {
+            const int e = tid + 256 * i, src = s0 + e;
+            st[i] = (e < span && src >= 0 && src < n) ? mono_at(x, n, channels, src) : 0.f;
+        }
+    };
+    if (ahead) request(tile_begin);
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         __syncthreads();                                               // the previous tile's reads are done (and the tables are in)
-        const int s0 = tile * blocks * orig - width;
-        for (int e = tid; e < span; e += 256) {
-            const int src = s0 + e;
-            xs[e] = (src >= 0 && src < n) ? mono_at(x, n, channels, src) : 0.f;
+        if (ahead) {
+#pragma unroll
+            for (int i = 0; i < kStage; ++i)
+                if (tid + 256 * i < span) xs[tid + 256 * i] = st[i];
+        } else {
+            const int s0 = tile * blocks * orig - width;
+            for (int e = tid; e < span; e += 256) {
+                const int src = s0 + e;
+                xs[e] = (src >= 0 && src < n) ? mono_at(x, n, channels, src) : 0.f;
+            }
         }
         __syncthreads();
+        if (ahead && tile + 1 < tile_end) request(tile + 1);
         const int o_base = tile * blocks * nw;
         const int n_here = min(blocks * nw, n_out - o_base);
         auto dot = [&](int il, int p) {
@@ -532,6 +554,127 @@ __global__ __launch_bounds__(256) void resample_generic_lds_kernel(
                 const float acc = dot(il, p);
                 y[o_base + e] = acc;
                 peak = fmaxf(peak, fabsf(acc));
+            }
+        }
+    }
+    __shared__ float s_peak[4];
+    peak = wave_max(peak);
+    if ((tid & 63) == 0) s_peak[tid >> 6] = peak;
+    __syncthreads();
+    if (tid == 0) {
+        const float m = fmaxf(fmaxf(s_peak[0], s_peak[1]), fmaxf(s_peak[2], s_peak[3]));
+        if (m > 0.f) atomicMax(&peak_keys[clip], __float_as_uint(m));
+    }
+}
+
+// The same for new_rate % 4 == 0 (441:160, 441:320 ...: the 44.1 / 22.05 / 11.025 kHz sources): a thread computes FOUR
+// consecutive outputs of one input block.  Their spans start only orig / new samples apart, so they share one window
+// of samples -- one LDS read per sample for four FMAs instead of one read per FMA -- and the four phases' taps for the
+// window position m sit side by side ([quad][m][4], absolute tap index, zero outside a phase's own span): one 16-byte
+// read.  Row stride 4 * lqs words with lqs odd: the 16 lanes of a b128 read pass hit all 64 banks.  Same accumulation
+// order per output as the kernels above.
+template <typename TIn, int kStage>
+__global__ __launch_bounds__(256) void resample_generic_quad_kernel(
+    const TIn* __restrict__ pcm_in, const int64_t* __restrict__ in_off, const int32_t* __restrict__ in_len,
+    int channels, const ResamplePlanHeader* __restrict__ plan, float* __restrict__ pcm_out,
+    const int64_t* __restrict__ out_off, int32_t* __restrict__ out_len, unsigned* __restrict__ peak_keys,
+    int blocks, int lqs, int tiles_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) float g_smem[];
+    const int clip = blockIdx.y, tid = threadIdx.x;
+    const int n = in_len[clip];
+    const int orig = plan->orig_rate, nw = plan->new_rate, width = plan->width, row = plan->taps_row;
+    const int nq = nw >> 2;
+    const int n_out = (int)(((int64_t)nw * n + orig - 1) / orig);
+    if (blockIdx.x == 0 && tid == 0) out_len[clip] = n_out;
+    const int n_blocks = (n_out + nw - 1) / nw;
+    const int n_tiles = (n_blocks + blocks - 1) / blocks;
+    const int tile_begin = blockIdx.x * tiles_per_wg;
+    const int tile_end = min(tile_begin + tiles_per_wg, n_tiles);
+    if (tile_begin >= tile_end) return;
+    const int32_t* __restrict__ lo = reinterpret_cast<const int32_t*>(plan + 1);
+    const int32_t* __restrict__ hi = lo + nw;
+    const float* __restrict__ taps = reinterpret_cast<const float*>(hi + nw);
+    float* taps_q = g_smem;                                            // [nq][lqs][4]
+    int* w0_s = reinterpret_cast<int*>(g_smem + nq * lqs * 4);         // [nq] first tap index of the quad's window
+    float* xs = reinterpret_cast<float*>(w0_s + nq);                   // [blocks * orig + 2 width + lqs]
+    for (int q = tid; q < nq; q += 256) w0_s[q] = min(min(lo[4 * q], lo[4 * q + 1]), min(lo[4 * q + 2], lo[4 * q + 3]));
+    for (int e = tid; e < nq * lqs * 4; e += 256) {
+        const int q = e / (lqs * 4), r = e - q * (lqs * 4);
+        const int m = r >> 2, p = 4 * q + (r & 3);
+        const int k = min(min(lo[4 * q], lo[4 * q + 1]), min(lo[4 * q + 2], lo[4 * q + 3])) + m;
+        taps_q[e] = (k >= lo[p] && k < hi[p]) ? taps[(size_t)p * row + k] : 0.f;
+    }
+    const TIn* __restrict__ x = pcm_in + in_off[clip];
+    float* __restrict__ y = pcm_out + out_off[clip];
+    const int span = blocks * orig + 2 * width;
+    for (int e = tid; e < lqs; e += 256) xs[span + e] = 0.f;           // the zero taps at the end of the last block's rows read this
+    const bool y_vec = (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    float peak = 0.f;
+    // spans of up to kStage (16 or 24, the host picks the instantiation) samples per thread are requested a tile ahead
+    // (registers), so that the HBM round trip of tile t + 1 runs under the arithmetic of tile t; longer spans are
+    // staged in place
+    const bool ahead = span <= kStage * 256;
+    float st[kStage];
+    auto request = [&](int tile) {
+        const int s0 = tile * blocks * orig - width;
+#pragma unroll
+        for (int i = 0; i < kStage; ++i) {
+            const int e = tid + 256 * i, src = s0 + e;
+            st[i] = (e < span && src >= 0 && src < n) ? mono_at(x, n, channels, src) : 0.f;
+        }
+    };
+    if (ahead) request(tile_begin);
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        __syncthreads();
+        if (ahead) {
+#pragma unroll
+            for (int i = 0; i < kStage; ++i)
+                if (tid + 256 * i < span) xs[tid + 256 * i] = st[i];
+        } else {
+            const int s0 = tile * blocks * orig - width;
+            for (int e = tid; e < span; e += 256) {
+                const int src = s0 + e;
+                xs[e] = (src >= 0 && src < n) ? mono_at(x, n, channels, src) : 0.f;
+            }
+        }
+        __syncthreads();
+        if (ahead && tile + 1 < tile_end) request(tile + 1);
+        const int o_base = tile * blocks * nw;                          // a multiple of 4
+        const int n_here = min(blocks * nw, n_out - o_base);
+        for (int e = tid; e < blocks * nq; e += 256) {
+            const int il = e / nq, q = e - il * nq;
+            const int ol = il * nw + 4 * q;
+            if (ol >= n_here) continue;
+            const float* __restrict__ xp = xs + il * orig + w0_s[q];
+            const f32x4* __restrict__ tq = reinterpret_cast<const f32x4*>(taps_q + (size_t)q * lqs * 4);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int m0 = 0; m0 < lqs - 1; m0 += 4) {                   // lqs - 1 is a multiple of 4
+                float x4[4];
+                f32x4 t4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    x4[j] = xp[m0 + j];
+                    t4[j] = tq[m0 + j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc.x = fmaf(t4[j].x, x4[j], acc.x);
+                    acc.y = fmaf(t4[j].y, x4[j], acc.y);
+                    acc.z = fmaf(t4[j].z, x4[j], acc.z);
+                    acc.w = fmaf(t4[j].w, x4[j], acc.w);
+                }
+            }
+            if (y_vec && ol + 4 <= n_here) {
+                *reinterpret_cast<f32x4*>(y + o_base + ol) = acc;
+                peak = fmaxf(peak, fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))));
+            } else {
+                const float a[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (ol + c < n_here) {
+                        y[o_base + ol + c] = a[c];
+                        peak = fmaxf(peak, fabsf(a[c]));
+                    }
             }
         }
     }
@@ -807,7 +950,54 @@ static int resample_peak_impl(const TIn* pcm_in, const int64_t* in_offsets, cons
             const bool via_lds = (orig & 1) && orig >= 3 && blocks >= 64 && fixed + blocks * (orig + nw) <= words;
             const long per_block = orig + (via_lds ? nw : 0);
             if (fixed + blocks * per_block > words) blocks = (words - fixed) / per_block;
-            if (!lds_off && fixed < words && blocks >= 1) {
+            // new_rate % 4 == 0: four outputs per thread off one window of samples
+            int lq = 0;
+            if ((nw & 3) == 0)
+                for (int q = 0; q < nw / 4; ++q) {
+                    int l0 = hlo[4 * q], h1 = hhi[4 * q];
+                    for (int c = 1; c < 4; ++c) {
+                        l0 = hlo[4 * q + c] < l0 ? hlo[4 * q + c] : l0;
+                        h1 = hhi[4 * q + c] > h1 ? hhi[4 * q + c] : h1;
+                    }
+                    lq = h1 - l0 > lq ? h1 - l0 : lq;
+                }
+            const int lqs = ((lq + 3) & ~3) + 1;
+            const long fixed_q = (long)nw * lqs + nw / 4 + 2L * hp->width + lqs;
+            // a tile is (input block, quad) items for 256 threads: as many blocks as fill whole rounds of them
+            // -- the fewest that leave at most a tenth of the last round idle, while the span still fits the registers
+            // that prefetch it (24 samples per thread) and the LDS
+            long blocks_q = 0;
+            if ((nw & 3) == 0) {
+                const long nq = nw / 4;
+                double best = 0.0;
+                for (long b = 1; b <= 4096; ++b) {
+                    if (fixed_q + b * orig > words || (b > 1 && b * orig + 2L * hp->width > 24 * 256)) break;
+                    const long items = b * nq;
+                    const double util = (double)items / (256.0 * ((items + 255) / 256));
+                    if (util > best + 1e-9) {
+                        best = util;
+                        blocks_q = b;
+                    }
+                    if (util >= 0.9 && items >= (tile_env > 0 ? tile_env / 4 : 240)) break;
+                }
+            }
+            static const bool quad_off = getenv("STTFE_RESAMPLE_GENERIC_NOQUAD") != nullptr;     // A/B knob
+            if (!lds_off && !quad_off && lq > 0 && fixed_q < words && blocks_q >= 1) {
+                const long tile_out = blocks_q * nw;
+                const int tiles_per_wg = (int)(tile_out >= 32768 ? 1 : (32768 + tile_out - 1) / tile_out);
+                const int64_t n_tiles = ((max_out + nw - 1) / nw + blocks_q - 1) / blocks_q;
+                int bx = (int)((n_tiles + tiles_per_wg - 1) / tiles_per_wg);
+                bx = bx < 1 ? 1 : bx;
+                const size_t lds = (size_t)(fixed_q + blocks_q * orig) * 4;
+                if (blocks_q * orig + 2L * hp->width <= 16 * 256)
+                    hipLaunchKernelGGL((resample_generic_quad_kernel<TIn, 16>), dim3(bx, batch), dim3(256), lds, stream, pcm_in,
+                                       in_offsets, in_lengths, channels, dp, pcm_out, out_offsets, out_lengths, keys,
+                                       (int)blocks_q, lqs, tiles_per_wg);
+                else
+                    hipLaunchKernelGGL((resample_generic_quad_kernel<TIn, 24>), dim3(bx, batch), dim3(256), lds, stream, pcm_in,
+                                       in_offsets, in_lengths, channels, dp, pcm_out, out_offsets, out_lengths, keys,
+                                       (int)blocks_q, lqs, tiles_per_wg);
+            } else if (!lds_off && fixed < words && blocks >= 1) {
                 const long tile_out = blocks * nw;
                 const int tiles_per_wg = (int)(tile_out >= 32768 ? 1 : (32768 + tile_out - 1) / tile_out);
                 const int64_t n_tiles = ((max_out + nw - 1) / nw + blocks - 1) / blocks;
