@@ -567,13 +567,13 @@ __global__ __launch_bounds__(256) void resample_generic_lds_kernel(
     }
 }
 
-// The same for new_rate % 4 == 0 (441:160, 441:320 ...: the 44.1 / 22.05 / 11.025 kHz sources): a thread computes FOUR
-// consecutive outputs of one input block.  Their spans start only orig / new samples apart, so they share one window
+// The same for new_rate % 4 == 0 (441:160, 441:320 ...: the 44.1 / 22.05 / 11.025 kHz sources): a thread computes
+// P = 4 consecutive outputs of one input block (P = 2 compiles too; it was slower than one output per thread).  Their spans start only orig / new samples apart, so they share one window
 // of samples -- one LDS read per sample for four FMAs instead of one read per FMA -- and the four phases' taps for the
 // window position m sit side by side ([quad][m][4], absolute tap index, zero outside a phase's own span): one 16-byte
 // read.  Row stride 4 * lqs words with lqs odd: the 16 lanes of a b128 read pass hit all 64 banks.  Same accumulation
 // order per output as the kernels above.
-template <typename TIn, int kStage>
+template <typename TIn, int kStage, int P>
 __global__ __launch_bounds__(256) void resample_generic_quad_kernel(
     const TIn* __restrict__ pcm_in, const int64_t* __restrict__ in_off, const int32_t* __restrict__ in_len,
     int channels, const ResamplePlanHeader* __restrict__ plan, float* __restrict__ pcm_out,
@@ -583,7 +583,9 @@ __global__ __launch_bounds__(256) void resample_generic_quad_kernel(
     const int clip = blockIdx.y, tid = threadIdx.x;
     const int n = in_len[clip];
     const int orig = plan->orig_rate, nw = plan->new_rate, width = plan->width, row = plan->taps_row;
-    const int nq = nw >> 2;
+    static_assert(P == 2 || P == 4, "outputs per thread");
+    typedef float fP __attribute__((ext_vector_type(P)));
+    const int nq = nw / P;                                             // groups of P consecutive phases
     const int n_out = (int)(((int64_t)nw * n + orig - 1) / orig);
     if (blockIdx.x == 0 && tid == 0) out_len[clip] = n_out;
     const int n_blocks = (n_out + nw - 1) / nw;
@@ -594,21 +596,27 @@ __global__ __launch_bounds__(256) void resample_generic_quad_kernel(
     const int32_t* __restrict__ lo = reinterpret_cast<const int32_t*>(plan + 1);
     const int32_t* __restrict__ hi = lo + nw;
     const float* __restrict__ taps = reinterpret_cast<const float*>(hi + nw);
-    float* taps_q = g_smem;                                            // [nq][lqs][4]
-    int* w0_s = reinterpret_cast<int*>(g_smem + nq * lqs * 4);         // [nq] first tap index of the quad's window
+    float* taps_q = g_smem;                                            // [nq][lqs][P]
+    int* w0_s = reinterpret_cast<int*>(g_smem + nq * lqs * P);         // [nq] first tap index of the group's window
     float* xs = reinterpret_cast<float*>(w0_s + nq);                   // [blocks * orig + 2 width + lqs]
-    for (int q = tid; q < nq; q += 256) w0_s[q] = min(min(lo[4 * q], lo[4 * q + 1]), min(lo[4 * q + 2], lo[4 * q + 3]));
-    for (int e = tid; e < nq * lqs * 4; e += 256) {
-        const int q = e / (lqs * 4), r = e - q * (lqs * 4);
-        const int m = r >> 2, p = 4 * q + (r & 3);
-        const int k = min(min(lo[4 * q], lo[4 * q + 1]), min(lo[4 * q + 2], lo[4 * q + 3])) + m;
+    auto group_lo = [&](int q) {
+        int l0 = lo[P * q];
+#pragma unroll
+        for (int c = 1; c < P; ++c) l0 = min(l0, lo[P * q + c]);
+        return l0;
+    };
+    for (int q = tid; q < nq; q += 256) w0_s[q] = group_lo(q);
+    for (int e = tid; e < nq * lqs * P; e += 256) {
+        const int q = e / (lqs * P), r = e - q * (lqs * P);
+        const int m = r / P, p = P * q + (r - m * P);
+        const int k = group_lo(q) + m;
         taps_q[e] = (k >= lo[p] && k < hi[p]) ? taps[(size_t)p * row + k] : 0.f;
     }
     const TIn* __restrict__ x = pcm_in + in_off[clip];
     float* __restrict__ y = pcm_out + out_off[clip];
     const int span = blocks * orig + 2 * width;
     for (int e = tid; e < lqs; e += 256) xs[span + e] = 0.f;           // the zero taps at the end of the last block's rows read this
-    const bool y_vec = (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    const bool y_vec = (reinterpret_cast<uintptr_t>(y) & (4 * P - 1)) == 0;
     float peak = 0.f;
     // spans of up to kStage (16 or 24, the host picks the instantiation) samples per thread are requested a tile ahead
     // (registers), so that the HBM round trip of tile t + 1 runs under the arithmetic of tile t; longer spans are
@@ -639,41 +647,38 @@ __global__ __launch_bounds__(256) void resample_generic_quad_kernel(
         }
         __syncthreads();
         if (ahead && tile + 1 < tile_end) request(tile + 1);
-        const int o_base = tile * blocks * nw;                          // a multiple of 4
+        const int o_base = tile * blocks * nw;                          // a multiple of P
         const int n_here = min(blocks * nw, n_out - o_base);
         for (int e = tid; e < blocks * nq; e += 256) {
             const int il = e / nq, q = e - il * nq;
-            const int ol = il * nw + 4 * q;
+            const int ol = il * nw + P * q;
             if (ol >= n_here) continue;
             const float* __restrict__ xp = xs + il * orig + w0_s[q];
-            const f32x4* __restrict__ tq = reinterpret_cast<const f32x4*>(taps_q + (size_t)q * lqs * 4);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const fP* __restrict__ tq = reinterpret_cast<const fP*>(taps_q + (size_t)q * lqs * P);
+            fP acc = 0.f;
             for (int m0 = 0; m0 < lqs - 1; m0 += 4) {                   // lqs - 1 is a multiple of 4
                 float x4[4];
-                f32x4 t4[4];
+                fP t4[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     x4[j] = xp[m0 + j];
                     t4[j] = tq[m0 + j];
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc.x = fmaf(t4[j].x, x4[j], acc.x);
-                    acc.y = fmaf(t4[j].y, x4[j], acc.y);
-                    acc.z = fmaf(t4[j].z, x4[j], acc.z);
-                    acc.w = fmaf(t4[j].w, x4[j], acc.w);
-                }
-            }
-            if (y_vec && ol + 4 <= n_here) {
-                *reinterpret_cast<f32x4*>(y + o_base + ol) = acc;
-                peak = fmaxf(peak, fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))));
-            } else {
-                const float a[4] = {acc.x, acc.y, acc.z, acc.w};
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                    for (int c = 0; c < P; ++c) acc[c] = fmaf(t4[j][c], x4[j], acc[c]);
+            }
+            if (y_vec && ol + P <= n_here) {
+                *reinterpret_cast<fP*>(y + o_base + ol) = acc;
+#pragma unroll
+                for (int c = 0; c < P; ++c) peak = fmaxf(peak, fabsf(acc[c]));
+            } else {
+#pragma unroll
+                for (int c = 0; c < P; ++c)
                     if (ol + c < n_here) {
-                        y[o_base + ol + c] = a[c];
-                        peak = fmaxf(peak, fabsf(a[c]));
+                        y[o_base + ol + c] = acc[c];
+                        peak = fmaxf(peak, fabsf(acc[c]));
                     }
             }
         }
@@ -950,25 +955,28 @@ static int resample_peak_impl(const TIn* pcm_in, const int64_t* in_offsets, cons
             const bool via_lds = (orig & 1) && orig >= 3 && blocks >= 64 && fixed + blocks * (orig + nw) <= words;
             const long per_block = orig + (via_lds ? nw : 0);
             if (fixed + blocks * per_block > words) blocks = (words - fixed) / per_block;
-            // new_rate % 4 == 0: four outputs per thread off one window of samples
+            // even new_rate: P = 4 or 2 consecutive outputs per thread off one window of samples
+            // (P = 2 for the other even rates -- 3:2, 1:2, 9:10, 11:10 -- measured slower than one output per thread:
+            // 0.18 -> 0.23, 0.26 -> 0.28, 0.23 -> 0.26 ms)
+            const int P = (nw & 3) == 0 ? 4 : 0;
             int lq = 0;
-            if ((nw & 3) == 0)
-                for (int q = 0; q < nw / 4; ++q) {
-                    int l0 = hlo[4 * q], h1 = hhi[4 * q];
-                    for (int c = 1; c < 4; ++c) {
-                        l0 = hlo[4 * q + c] < l0 ? hlo[4 * q + c] : l0;
-                        h1 = hhi[4 * q + c] > h1 ? hhi[4 * q + c] : h1;
+            if (P)
+                for (int q = 0; q < nw / P; ++q) {
+                    int l0 = hlo[P * q], h1 = hhi[P * q];
+                    for (int c = 1; c < P; ++c) {
+                        l0 = hlo[P * q + c] < l0 ? hlo[P * q + c] : l0;
+                        h1 = hhi[P * q + c] > h1 ? hhi[P * q + c] : h1;
                     }
                     lq = h1 - l0 > lq ? h1 - l0 : lq;
                 }
             const int lqs = ((lq + 3) & ~3) + 1;
-            const long fixed_q = (long)nw * lqs + nw / 4 + 2L * hp->width + lqs;
-            // a tile is (input block, quad) items for 256 threads: as many blocks as fill whole rounds of them
-            // -- the fewest that leave at most a tenth of the last round idle, while the span still fits the registers
-            // that prefetch it (24 samples per thread) and the LDS
+            const long fixed_q = (long)nw * lqs + (P ? nw / P : 0) + 2L * hp->width + lqs;
+            // a tile is (input block, phase group) items for 256 threads: the fewest blocks that leave at most a tenth
+            // of the last round idle, while the span still fits the registers that prefetch it (24 samples per thread)
+            // and the LDS
             long blocks_q = 0;
-            if ((nw & 3) == 0) {
-                const long nq = nw / 4;
+            if (P) {
+                const long nq = nw / P;
                 double best = 0.0;
                 for (long b = 1; b <= 4096; ++b) {
                     if (fixed_q + b * orig > words || (b > 1 && b * orig + 2L * hp->width > 24 * 256)) break;
@@ -989,14 +997,14 @@ static int resample_peak_impl(const TIn* pcm_in, const int64_t* in_offsets, cons
                 int bx = (int)((n_tiles + tiles_per_wg - 1) / tiles_per_wg);
                 bx = bx < 1 ? 1 : bx;
                 const size_t lds = (size_t)(fixed_q + blocks_q * orig) * 4;
-                if (blocks_q * orig + 2L * hp->width <= 16 * 256)
-                    hipLaunchKernelGGL((resample_generic_quad_kernel<TIn, 16>), dim3(bx, batch), dim3(256), lds, stream, pcm_in,
-                                       in_offsets, in_lengths, channels, dp, pcm_out, out_offsets, out_lengths, keys,
-                                       (int)blocks_q, lqs, tiles_per_wg);
-                else
-                    hipLaunchKernelGGL((resample_generic_quad_kernel<TIn, 24>), dim3(bx, batch), dim3(256), lds, stream, pcm_in,
-                                       in_offsets, in_lengths, channels, dp, pcm_out, out_offsets, out_lengths, keys,
-                                       (int)blocks_q, lqs, tiles_per_wg);
+                const bool s16k = blocks_q * orig + 2L * hp->width <= 16 * 256;
+#define STTFE_LAUNCH_GROUPS(S, PP)                                                                                   \
+    hipLaunchKernelGGL((resample_generic_quad_kernel<TIn, S, PP>), dim3(bx, batch), dim3(256), lds, stream, pcm_in,   \
+                       in_offsets, in_lengths, channels, dp, pcm_out, out_offsets, out_lengths, keys, (int)blocks_q,  \
+                       lqs, tiles_per_wg)
+                if (s16k) STTFE_LAUNCH_GROUPS(16, 4);
+                else STTFE_LAUNCH_GROUPS(24, 4);
+#undef STTFE_LAUNCH_GROUPS
             } else if (!lds_off && fixed < words && blocks >= 1) {
                 const long tile_out = blocks * nw;
                 const int tiles_per_wg = (int)(tile_out >= 32768 ? 1 : (32768 + tile_out - 1) / tile_out);
