@@ -6,9 +6,9 @@
 // x / (max|x| + 1e-8) (:78-81), trim to the first..last sample above 0.01 * max (:84-91).
 //
 // Kernel 1a (decimate_peak<ORIG>): integer decimation ORIG:1 (48 -> 16 kHz: ORIG = 3, 41 taps;
-//   32 -> 16 kHz: ORIG = 2, 28 taps).  Persistent 256-thread workgroups walk (clip, run of 8 tiles) items,
-//   clip-major over an LDS prefix of the clips' run counts (up to 2048 clips; one item per workgroup
-//   beyond that).  Per 1024-output tile the input span
+//   32 -> 16 kHz: ORIG = 2, 28 taps).  A 256-thread workgroup takes one (clip, run of 8 tiles) item; with
+//   STTFE_DECIMATE_PERSIST=1 resident workgroups walk the items instead, clip-major over an LDS prefix of the
+//   clips' run counts (up to 2048 clips).  Per 1024-output tile the input span
 //   is read from HBM once with lane-contiguous loads and de-interleaved into ORIG phase rows in LDS
 //   (row r holds padded[ORIG m + r]), so that out[i] = sum_r sum_j h[ORIG j + r] * row_r[i + j] and a
 //   thread that owns 4 consecutive outputs reads each row with five conflict-free ds_read_b128
@@ -908,7 +908,11 @@ static int resample_peak_impl(const TIn* pcm_in, const int64_t* in_offsets, cons
                           (hp->orig_rate == 2 || hp->orig_rate == 3 || hp->orig_rate == 4 || hp->orig_rate == 6);
         if (fast) {
             static const int tpb_env = getenv("STTFE_DECIMATE_TPB") ? atoi(getenv("STTFE_DECIMATE_TPB")) : 0;   // tuning knobs
-            static const int persist_env = getenv("STTFE_DECIMATE_PERSIST") ? atoi(getenv("STTFE_DECIMATE_PERSIST")) : 1;
+            // one item per workgroup by default: on the final kernel (8-tile items, one peak atomic per workgroup, vector
+            // staging) the persistent form measured 3-4 % slower (float 0.183 / 0.176 ms, int16 0.125 / 0.122 ms) and, holding
+            // every CU for the whole launch, overlaps less with another stream's kernels (config 3 fused, two batches in
+            // flight: 0.378 / 0.357 ms per step); STTFE_DECIMATE_PERSIST=1 selects it
+            static const int persist_env = getenv("STTFE_DECIMATE_PERSIST") ? atoi(getenv("STTFE_DECIMATE_PERSIST")) : 0;
             const int tiles_per_block = tpb_env > 0 ? tpb_env : 8;     // 4 / 6 / 8 / 12 / 16: 0.188 / 0.179 / 0.177 / 0.183 / 0.186 ms (config 3)
             const int64_t n_tiles = (max_out + rs::kTile - 1) / rs::kTile;
             int bx = (int)((n_tiles + tiles_per_block - 1) / tiles_per_block);

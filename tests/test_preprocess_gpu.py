@@ -163,3 +163,33 @@ def test_decimator_empty_clips_between_others():
         got = p.pcm[o:o + exp.shape[0]].cpu().numpy()
         assert np.abs(got - exp).max() <= 2e-6, (i, n)
         assert peaks[i] == np.abs(got).max()
+
+
+def test_decimator_persistent_form_in_a_child_process():
+    """STTFE_DECIMATE_PERSIST=1 (read once per process) selects the persistent-workgroup form of the decimator: a child
+    process runs it on clips around the item boundaries, float and int16, and holds it to the oracle."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch
+from oracle import resample as R
+from speech_to_text_amd.preprocess import GpuAudioPreprocessor
+from speech_to_text_amd.synth import synth_clip
+pre = GpuAudioPreprocessor(normalize=False, trim_silence=False, min_duration=0.0, max_duration=1e9, device="cuda:0")
+item = 3 * 1024 * 8
+lens = [item, item + 1, 2 * item + 3 * 1024, 5, 17 * 3 * 1024 + 7, 3 * item - 2, 40000]
+clips = [synth_clip(np.random.default_rng(900 + i), n, sample_rate=48000, zero_block=False) for i, n in enumerate(lens)]
+for as16 in (False, True):
+    src = [np.clip(np.round(c * 32767.0), -32768, 32767).astype(np.int16) for c in clips] if as16 else clips
+    p = pre.preprocess_batch(src, 48000)
+    for i, c in enumerate(src):
+        ref = R.resample(c.astype(np.float32) / 32768.0 if as16 else c, 48000, 16000)
+        got = p.clip(i)[0].cpu().numpy()
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= 2e-6, (as16, lens[i])
+print("persistent form ok")
+'''
+    env = dict(os.environ, STTFE_DECIMATE_PERSIST="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "persistent form ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
