@@ -486,8 +486,43 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
             }
         }
     };
-    float raw0[28], raw1[28];                      // the two passes of the NEXT tile, loaded a whole tile ahead
-    bool raw_ready = false;                        // raw0 / raw1 already hold the first tile of the current item
+    bool raw_ready = false;                        // raw4 already holds the first tile of the current item
+    // The PCM of the NEXT tile is requested a whole tile ahead.  Interior tiles (every sample of the wave's 12 frames
+    // inside the clip, 16-byte aligned: all but a clip's first and last tiles) as NINE 16-byte loads per lane over the wave's contiguous 2160-sample span instead
+    // of 56 dword loads (a dword load of this shape costs the wave ~25-35 cycles of issue: tools/stamps.py put 1.3-1.9 k
+    // cycles per tile there; edge tiles load the same 36 span elements per lane one by one, with the reflection / zero
+    // padding rules), and are dealt to the lanes through the wave's own slab at the top of the next tile,
+    // while the slab is free: sample s sits at float s + 20 (s / 320), which puts the three pairs' rows of one load
+    // step on disjoint banks (pair p reads 320 p + j + 20 m; 320 = 0 mod 32 banks, the skew moves pair p by 20 p).
+    constexpr int kSpanQuads = (11 * kHop + kNfft) / 4;         // 540 float4 per wave and tile
+    constexpr int kStageLoads = (kSpanQuads + 63) / 64;         // 9
+    f32x4 raw4[kStageLoads];
+    auto request_tile = [&](const float* __restrict__ xb, int n_valid, int t0) {
+        const int first = kHop * (t0 + wave * kFramesPerWave) - kNfft / 2;       // wave-uniform
+        constexpr int kSpan = 11 * kHop + kNfft;
+        if (first >= 0 && first + kSpan <= n_valid && (reinterpret_cast<uintptr_t>(xb + first) & 15) == 0) {
+            const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(xb + first);
+#pragma unroll
+            for (int q = 0; q < kStageLoads; ++q) raw4[q] = src[min(lane + 64 * q, kSpanQuads - 1)];
+        } else if (mode != kModeTorchVarlen && first >= n_valid && first + kSpan <= kMaxSamples) {
+            // the wave's whole span lies in the zero padding to 30 s
+#pragma unroll
+            for (int q = 0; q < kStageLoads; ++q) raw4[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            // clip edges (reflection at the start / at the 30 s end or the clip's own end, zero padding), unaligned clips
+            const int lim = mode == kModeTorchVarlen ? n_valid : kMaxSamples;
+#pragma unroll
+            for (int q = 0; q < kStageLoads; ++q) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    int idx = first + 4 * min(lane + 64 * q, kSpanQuads - 1) + c;
+                    idx = idx < 0 ? -idx : idx;                                       // reflect padding (center=True) ...
+                    idx = idx >= lim ? 2 * (lim - 1) - idx : idx;                     // ... of the 30 s buffer / of the clip
+                    raw4[q][c] = (idx >= 0 && idx < n_valid) ? xb[idx] : 0.0f;        // zero padding to 30 s
+                }
+            }
+        }
+    };
 
     // zero the slabs once (pad cells are read by zero-weight MFMA steps and must be finite), stage tables.
     // Every global load of the staging is requested before the first LDS store: as copy loops (load, store, load, ...)
@@ -673,10 +708,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
       int32_t* clip_masks = reinterpret_cast<int32_t*>(smem + kMaskOff);
       if (tid < 3 * nm) clip_masks[tid] = mask_tbl[(size_t)clip * n_masks * 3 + tid];
       uint64_t melmask_lo = 0, melmask_hi = 0;
-      if (!raw_ready) {
-          load_pass(x, n_valid, tile_begin * kTileFrames, 0, raw0);
-          load_pass(x, n_valid, tile_begin * kTileFrames, 1, raw1);
-      }
+      if (!raw_ready) request_tile(x, n_valid, tile_begin * kTileFrames);
       raw_ready = false;
       float run_max = 0.0f;                         // mel energies (>= 1e-10 once any cell was produced)
       for (int tile = tile_begin; tile < tile_end; ++tile) {
@@ -684,6 +716,23 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 #ifdef STTFE_STAMPS
         if (tile == tile_begin) STAMP(11);
 #endif
+        float raw0[28], raw1[28];
+        {                                       // deal the tile's samples to the lanes through the wave's slab
+            wave_lds_sync();
+            f32x4* stage = reinterpret_cast<f32x4*>(my_rows);
+#pragma unroll
+            for (int q = 0; q < kStageLoads; ++q) {
+                const int u = min(lane + 64 * q, kSpanQuads - 1);
+                stage[u + 5 * (u / 80)] = raw4[q];
+            }
+            wave_lds_sync();
+            const float* rd = my_rows + 340 * pa_ + j;
+#pragma unroll
+            for (int m = 0; m < 28; ++m) {
+                raw0[m] = rd[20 * m + (m >= 16 ? 20 : 0)];
+                raw1[m] = rd[1020 + 20 * m + (m >= 16 ? 20 : 0)];
+            }
+        }
         {
             f2 ya[20], yb[20], pw0[11], pw1[11], q0[10], q1[10];
             f32x4 ra[10], rb[10];
@@ -710,8 +759,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         // next tile's PCM -- of this item, or the first tile of the workgroup's next item: issued now (few live
         // registers from here on), lands during the mel projection
         if (tile + 1 < tile_end) {
-            load_pass(x, n_valid, t0 + kTileFrames, 0, raw0);
-            load_pass(x, n_valid, t0 + kTileFrames, 1, raw1);
+            request_tile(x, n_valid, t0 + kTileFrames);
         } else if (next_item < n_items) {
             // (the empty asm makes these values opaque here: otherwise the compiler computes the 56 load indices and
             // bounds predicates of the next item at the top of this item and spills them across the whole tile loop)
@@ -722,8 +770,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
             const int64_t off_n = ((int64_t)__builtin_amdgcn_readfirstlane((int)(off_next >> 32)) << 32) |
                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)off_next);
             if (tb < min(n_tiles, first_pad_tile_of(nv))) {
-                load_pass(pcm + off_n, nv, tb * kTileFrames, 0, raw0);
-                load_pass(pcm + off_n, nv, tb * kTileFrames, 1, raw1);
+                request_tile(pcm + off_n, nv, tb * kTileFrames);
                 raw_ready = true;
             }
         }
@@ -993,6 +1040,15 @@ __device__ __forceinline__ void mel_unit_wave(const float* __restrict__ a_lane, 
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][2], bv[g][2], acc, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][3], bv[g][3], acc2, 0, 0, 0);
     }
+    {
+        constexpr int P = NG < 2 ? NG : 2;
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * P, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if (g + P < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+    }
     acc += acc2;
     float mv[4], yv[4];
 #pragma unroll
@@ -1054,7 +1110,12 @@ __global__ __launch_bounds__(64 * W, W / 4) void whisper_stft_mel_wave_kernel(
     auto const_frame_of = [=](int n_valid) {
         return whisper_const_frame(n_valid, n_frames, min(n_frames, min(n_tiles48, first_pad_tile_of(n_valid)) * kTileFrames), mode);
     };
-    auto wtiles_of = [=](int n_valid) { return min(n_wtiles, (const_frame_of(n_valid) + kWT - 1) / kWT); };
+    // (reference mode "padded": frame n_frames itself, the 3001st, counts for the per-clip maximum although it is cropped:
+    // clips that reach the end of the output get one more tile, of which only that frame is looked at)
+    auto wtiles_of = [=](int n_valid) {
+        const int cf = const_frame_of(n_valid);
+        return (mode == kModeTorchPadded && cf >= n_frames) ? (n_frames + kWT) / kWT : min(n_wtiles, (cf + kWT - 1) / kWT);
+    };
 
     // ---- tables: every global load requested before the first LDS store
     static_assert(sizeof(WhisperTablesHeader) % 16 == 0, "the mel weights behind the header are read as 16-byte words");
@@ -1358,6 +1419,7 @@ __global__ __launch_bounds__(64 * W, W / 4) void whisper_stft_mel_wave_kernel(
         }
         const int wt_begin = run * tiles_per_item;
         const int wt_end = min(wt_begin + tiles_per_item, wtiles_of(n_valid));
+        unsigned ticket_val = 0xffffffffu;
         const int key_frames = mode == kModeTorchVarlen ? 1 + n_valid / kHop : (mode == kModeTorchPadded ? n_frames + 1 : n_frames);
         const int const_frame = const_frame_of(n_valid);
         if (wt_begin < wt_end) {
@@ -1428,6 +1490,9 @@ __global__ __launch_bounds__(64 * W, W / 4) void whisper_stft_mel_wave_kernel(
                     load_pass(x, n_valid, t0 + kWT, 0, raw0);
                     load_pass(x, n_valid, t0 + kWT, 1, raw1);
                 } else if (next_item < n_items) {
+                    // the ticket taken at the top of this item is read HERE, in front of the prefetch: behind it the wait
+                    // for the atomic's value would also wait for these 56 loads
+                    ticket_val = (unsigned)__builtin_amdgcn_readfirstlane((int)my_ticket);
                     int nv = clamp_len(__builtin_amdgcn_readfirstlane(len_next)), tb = __builtin_amdgcn_readfirstlane(run_nx * tiles_per_item);
                     asm volatile("" : "+v"(nv), "+v"(tb));
                     nv = __builtin_amdgcn_readfirstlane(nv);
@@ -1524,8 +1589,9 @@ __global__ __launch_bounds__(64 * W, W / 4) void whisper_stft_mel_wave_kernel(
             if (lane == 0 && run_max > 0.0f)
                 atomicMax(&keys[(size_t)clip * kKeysPerClip], float_to_key(__log2f(run_max) * 0.30102999566398120f));
         }
+        if (next_item < n_items && ticket_val == 0xffffffffu) ticket_val = (unsigned)__builtin_amdgcn_readfirstlane((int)my_ticket);
         const int after_next = (next_item < n_items)
-                                   ? (int)min((unsigned)__builtin_amdgcn_readfirstlane((int)my_ticket) + 2u * (unsigned)total_waves, (unsigned)n_items)
+                                   ? (int)min((unsigned long long)ticket_val + 2ull * (unsigned)total_waves, (unsigned long long)n_items)
                                    : n_items;
         item = next_item;
         clip_cur = clip_nx;

@@ -12,6 +12,13 @@ __device__ __forceinline__ void mfma_block(f32x4& a0, f32x4& a1, f32x4& a2, f32x
     a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a2, 0, 0, 0);
     a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a3, 0, 0, 0);
 }
+typedef short bf8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void mfma_bf16_block(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3, bf8 x, bf8 y) {
+    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, a3, 0, 0, 0);
+}
 __device__ __forceinline__ void valu_block(f2 (&p)[8], f2 c, f2 d) {
 #pragma unroll
     for (int r = 0; r < 2; ++r)
@@ -27,12 +34,20 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, unsigned long lo
     for (int i = 0; i < 8; ++i) p[i] = f2{threadIdx.x * 1e-3f + i, 1.f};
     const float x = threadIdx.x * 1e-4f, y = 1.0f - x;
     const f2 c = {1.0001f, 0.9999f}, d = {0.5f, 0.25f};
+    bf8 bx, by;
+    for (int i = 0; i < 8; ++i) { bx[i] = (short)(0x3f80 + threadIdx.x + i); by[i] = (short)(0x3f00 + i); }
+    const bool do_bf16 = ((MODE == 6 || MODE == 7) && roleA) || MODE == 8;
     const bool do_mfma = (MODE == 0) || ((MODE == 2 || MODE == 3) && roleA);
-    const bool do_valu = (MODE == 1) || (MODE == 2 && !roleA) || (MODE == 4 && roleA);
+    const bool do_valu = (MODE == 1) || (MODE == 2 && !roleA) || (MODE == 4 && roleA) || (MODE == 6 && !roleA);
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     if (MODE == 5) {
         if (roleA)
             for (int it = 0; it < iters; ++it) { mfma_block(a0, a1, a2, a3, x, y); valu_block(p, c, d); }
+    } else if (MODE == 9) {
+        if (roleA)
+            for (int it = 0; it < iters; ++it) { mfma_bf16_block(a0, a1, a2, a3, bx, by); valu_block(p, c, d); }
+    } else if (do_bf16) {
+        for (int it = 0; it < iters; ++it) mfma_bf16_block(a0, a1, a2, a3, bx, by);
     } else if (do_mfma) {
         for (int it = 0; it < iters; ++it) mfma_block(a0, a1, a2, a3, x, y);
     } else if (do_valu) {
@@ -48,8 +63,9 @@ int main() {
     float* out; (void)hipMalloc(&out, 8192);
     unsigned long long* cyc; (void)hipMalloc(&cyc, 64);
     const int iters = 20000;
-    const char* names[6] = {"MFMA | MFMA", "VALU | VALU", "MFMA | VALU", "MFMA | idle", "VALU | idle", "one wave: 4 MFMA + 16 pk_fma"};
-    for (int mode = 0; mode < 6; ++mode) {
+    const char* names[10] = {"MFMA | MFMA", "VALU | VALU", "MFMA | VALU", "MFMA | idle", "VALU | idle", "one wave: 4 MFMA + 16 pk_fma",
+                             "bf16 MFMA | VALU", "bf16 MFMA | idle", "bf16 MFMA | bf16 MFMA", "one wave: 4 bf16 MFMA + 16 pk_fma"};
+    for (int mode = 0; mode < 10; ++mode) {
         for (int rep = 0; rep < 2; ++rep) {
             if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(512), 0, 0, out, iters, cyc);
             if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(512), 0, 0, out, iters, cyc);
@@ -57,6 +73,10 @@ int main() {
             if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(256), dim3(512), 0, 0, out, iters, cyc);
             if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(256), dim3(512), 0, 0, out, iters, cyc);
             if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(256), dim3(512), 0, 0, out, iters, cyc);
+            if (mode == 6) hipLaunchKernelGGL(k<6>, dim3(256), dim3(512), 0, 0, out, iters, cyc);
+            if (mode == 7) hipLaunchKernelGGL(k<7>, dim3(256), dim3(512), 0, 0, out, iters, cyc);
+            if (mode == 8) hipLaunchKernelGGL(k<8>, dim3(256), dim3(512), 0, 0, out, iters, cyc);
+            if (mode == 9) hipLaunchKernelGGL(k<9>, dim3(256), dim3(512), 0, 0, out, iters, cyc);
             (void)hipDeviceSynchronize();
         }
         unsigned long long h[8];
