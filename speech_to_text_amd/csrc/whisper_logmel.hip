@@ -198,29 +198,13 @@ __device__ __forceinline__ void mel_unit_static(const float* __restrict__ a_lane
     const f32x4* __restrict__ a = reinterpret_cast<const f32x4*>(a_lane + AO);
     const f32x4* __restrict__ b = reinterpret_cast<const f32x4*>(b_lane + KS);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-    // every operand of the unit is requested before its first MFMA (distinct registers): read group by group into one
-    // register set, each group's reads waited out the LDS latency behind the previous group's four MFMAs
-    f32x4 av[NG], bv[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        av[g] = a[g * 64];
-        bv[g] = b[4 * g];
-    }
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][0], bv[g][0], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][1], bv[g][1], acc2, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][2], bv[g][2], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][3], bv[g][3], acc2, 0, 0, 0);
-    }
-    {   // pin the order: the reads of two groups up front, then {4 MFMAs, the reads of the group after next}
-        constexpr int P = NG < 2 ? NG : 2;
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * P, 0);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            if (g + P < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        }
+        const f32x4 av = a[g * 64], bv = b[4 * g];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc2, 0, 0, 0);
     }
     acc += acc2;
     float mv[4], yv[4];
@@ -260,9 +244,6 @@ __device__ __forceinline__ int whisper_const_frame(int n_valid, int n_frames, in
 
 #ifndef STTFE_WH_WAVES_PER_SIMD
 #define STTFE_WH_WAVES_PER_SIMD 2
-#endif
-#ifndef STTFE_WH_DEFAULT_FORM
-#define STTFE_WH_DEFAULT_FORM 0      // kernel 1 form: 0 = workgroup tiles, 8 / 12 = wave-independent (env STTFE_WH_KERNEL)
 #endif
 __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper_stft_mel_kernel(
     const float* __restrict__ pcm, const int64_t* __restrict__ offsets,
@@ -486,43 +467,8 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
             }
         }
     };
-    bool raw_ready = false;                        // raw4 already holds the first tile of the current item
-    // The PCM of the NEXT tile is requested a whole tile ahead.  Interior tiles (every sample of the wave's 12 frames
-    // inside the clip, 16-byte aligned: all but a clip's first and last tiles) as NINE 16-byte loads per lane over the wave's contiguous 2160-sample span instead
-    // of 56 dword loads (a dword load of this shape costs the wave ~25-35 cycles of issue: tools/stamps.py put 1.3-1.9 k
-    // cycles per tile there; edge tiles load the same 36 span elements per lane one by one, with the reflection / zero
-    // padding rules), and are dealt to the lanes through the wave's own slab at the top of the next tile,
-    // while the slab is free: sample s sits at float s + 20 (s / 320), which puts the three pairs' rows of one load
-    // step on disjoint banks (pair p reads 320 p + j + 20 m; 320 = 0 mod 32 banks, the skew moves pair p by 20 p).
-    constexpr int kSpanQuads = (11 * kHop + kNfft) / 4;         // 540 float4 per wave and tile
-    constexpr int kStageLoads = (kSpanQuads + 63) / 64;         // 9
-    f32x4 raw4[kStageLoads];
-    auto request_tile = [&](const float* __restrict__ xb, int n_valid, int t0) {
-        const int first = kHop * (t0 + wave * kFramesPerWave) - kNfft / 2;       // wave-uniform
-        constexpr int kSpan = 11 * kHop + kNfft;
-        if (first >= 0 && first + kSpan <= n_valid && (reinterpret_cast<uintptr_t>(xb + first) & 15) == 0) {
-            const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(xb + first);
-#pragma unroll
-            for (int q = 0; q < kStageLoads; ++q) raw4[q] = src[min(lane + 64 * q, kSpanQuads - 1)];
-        } else if (mode != kModeTorchVarlen && first >= n_valid && first + kSpan <= kMaxSamples) {
-            // the wave's whole span lies in the zero padding to 30 s
-#pragma unroll
-            for (int q = 0; q < kStageLoads; ++q) raw4[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        } else {
-            // clip edges (reflection at the start / at the 30 s end or the clip's own end, zero padding), unaligned clips
-            const int lim = mode == kModeTorchVarlen ? n_valid : kMaxSamples;
-#pragma unroll
-            for (int q = 0; q < kStageLoads; ++q) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    int idx = first + 4 * min(lane + 64 * q, kSpanQuads - 1) + c;
-                    idx = idx < 0 ? -idx : idx;                                       // reflect padding (center=True) ...
-                    idx = idx >= lim ? 2 * (lim - 1) - idx : idx;                     // ... of the 30 s buffer / of the clip
-                    raw4[q][c] = (idx >= 0 && idx < n_valid) ? xb[idx] : 0.0f;        // zero padding to 30 s
-                }
-            }
-        }
-    };
+    float raw0[28], raw1[28];                      // the two passes of the NEXT tile, loaded a whole tile ahead
+    bool raw_ready = false;                        // raw0 / raw1 already hold the first tile of the current item
 
     // zero the slabs once (pad cells are read by zero-weight MFMA steps and must be finite), stage tables.
     // Every global load of the staging is requested before the first LDS store: as copy loops (load, store, load, ...)
@@ -708,7 +654,10 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
       int32_t* clip_masks = reinterpret_cast<int32_t*>(smem + kMaskOff);
       if (tid < 3 * nm) clip_masks[tid] = mask_tbl[(size_t)clip * n_masks * 3 + tid];
       uint64_t melmask_lo = 0, melmask_hi = 0;
-      if (!raw_ready) request_tile(x, n_valid, tile_begin * kTileFrames);
+      if (!raw_ready) {
+          load_pass(x, n_valid, tile_begin * kTileFrames, 0, raw0);
+          load_pass(x, n_valid, tile_begin * kTileFrames, 1, raw1);
+      }
       raw_ready = false;
       float run_max = 0.0f;                         // mel energies (>= 1e-10 once any cell was produced)
       for (int tile = tile_begin; tile < tile_end; ++tile) {
@@ -716,23 +665,6 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 #ifdef STTFE_STAMPS
         if (tile == tile_begin) STAMP(11);
 #endif
-        float raw0[28], raw1[28];
-        {                                       // deal the tile's samples to the lanes through the wave's slab
-            wave_lds_sync();
-            f32x4* stage = reinterpret_cast<f32x4*>(my_rows);
-#pragma unroll
-            for (int q = 0; q < kStageLoads; ++q) {
-                const int u = min(lane + 64 * q, kSpanQuads - 1);
-                stage[u + 5 * (u / 80)] = raw4[q];
-            }
-            wave_lds_sync();
-            const float* rd = my_rows + 340 * pa_ + j;
-#pragma unroll
-            for (int m = 0; m < 28; ++m) {
-                raw0[m] = rd[20 * m + (m >= 16 ? 20 : 0)];
-                raw1[m] = rd[1020 + 20 * m + (m >= 16 ? 20 : 0)];
-            }
-        }
         {
             f2 ya[20], yb[20], pw0[11], pw1[11], q0[10], q1[10];
             f32x4 ra[10], rb[10];
@@ -759,7 +691,8 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         // next tile's PCM -- of this item, or the first tile of the workgroup's next item: issued now (few live
         // registers from here on), lands during the mel projection
         if (tile + 1 < tile_end) {
-            request_tile(x, n_valid, t0 + kTileFrames);
+            load_pass(x, n_valid, t0 + kTileFrames, 0, raw0);
+            load_pass(x, n_valid, t0 + kTileFrames, 1, raw1);
         } else if (next_item < n_items) {
             // (the empty asm makes these values opaque here: otherwise the compiler computes the 56 load indices and
             // bounds predicates of the next item at the top of this item and spills them across the whole tile loop)
@@ -770,7 +703,8 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
             const int64_t off_n = ((int64_t)__builtin_amdgcn_readfirstlane((int)(off_next >> 32)) << 32) |
                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)off_next);
             if (tb < min(n_tiles, first_pad_tile_of(nv))) {
-                request_tile(pcm + off_n, nv, tb * kTileFrames);
+                load_pass(pcm + off_n, nv, tb * kTileFrames, 0, raw0);
+                load_pass(pcm + off_n, nv, tb * kTileFrames, 1, raw1);
                 raw_ready = true;
             }
         }
@@ -985,633 +919,6 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 #endif
 }
 
-// =====================================================================================================================
-// Kernel 1, wave-independent form (round 3).  Same arithmetic, same keys, same output as whisper_stft_mel_kernel; what
-// changes is who works with whom.  Above, the four waves of a workgroup share a 48-frame tile: each transforms 12
-// frames, then all four meet at a barrier, project the whole tile (units spread over the waves) and meet again.  The
-// counters of that form (profiles/r2_whisper80_pmc.json) show no pipe saturated -- VALU 47 %, LDS 44 %, matrix 18 %
-// busy -- and waves parked: barriers couple the four waves' phases, so a wave's stalls become everybody's.
-// Here a wave owns its 12 frames from PCM to stores: transform, its own 12 panel rows (aliasing its own exchange slab,
-// as before), then ALL mel tiles of those 12 frames on the matrix cores (16-column MFMA tiles with 12 live columns: a
-// third more MFMAs, on a pipe that was 18 % busy) -- no workgroup barrier anywhere in the loop, so the waves of a SIMD
-// drift apart and one wave's matrix phase sits beside another's transform by itself.  The workgroup only shares the
-// tables (staged once) and the item plan, which is what lets W = 12 waves (three per SIMD) fit one CU's LDS:
-// 12 x 10.3 KB slabs + 23 KB tables + the plan.  Work items are (clip, run of 12-frame tiles) per WAVE, taken from the
-// same ticket counter; everything about an item is wave-uniform.
-namespace ww {
-constexpr int kWTile = 12;                       // frames per wave tile = wh::kFramesPerWave
-constexpr int kWTilesPerKeyTile = wh::kTileFrames / kWTile;      // 4: the min keys stay per 48-frame tile (kernel 2)
-template <int W>
-struct Lds {
-    static constexpr int kThreads = 64 * W;
-    static constexpr int kWinOff = W * wh::kSlabFloats;
-    static constexpr int kTwOff = kWinOff + 400;
-    static constexpr int kAfragOff = kTwOff + 20 * wh::kTwStride;
-    static constexpr int kMaskOff = kAfragOff + wh::kMaxAfragFloats;          // per wave: the current clip's masks
-    static constexpr int kPlanOff = kMaskOff + W * 3 * STTFE_MAX_MASKS;
-    static constexpr int kMaxPlanClips = W >= 12 ? 2560 : 3072;
-    static constexpr int kLdsFloats = kPlanOff + kMaxPlanClips + 1;
-    static_assert(kLdsFloats * 4 <= 163840, "one workgroup per CU: all of its LDS");
-};
-}  // namespace ww
-
-// One mel tile MT of a whole 12-frame wave tile of an NM-bin extractor (static plan).  Lanes whose MFMA column is
-// 12..15 read rows 0..3 again (same addresses: broadcasts) and store nothing; their maxima / minima repeat frames 0..3.
-template <int NM, int MT, bool kMask>
-__device__ __forceinline__ void mel_unit_wave(const float* __restrict__ a_lane, const float* __restrict__ b_lane,
-                                              float* __restrict__ out_u, unsigned (&o_r)[4], float mel_floor,
-                                              float y_bias, float& run_max, float& tile_min, unsigned tbits,
-                                              unsigned mbits, int lane, bool col_live) {
-    using P = wh::StaticPlan<NM>;
-    constexpr int KS = P::kstart[MT], NG = P::nsteps[MT] / 4, AO = P::aoff[MT];
-    const f32x4* __restrict__ a = reinterpret_cast<const f32x4*>(a_lane + AO);
-    const f32x4* __restrict__ b = reinterpret_cast<const f32x4*>(b_lane + KS);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 av[NG], bv[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        av[g] = a[g * 64];
-        bv[g] = b[4 * g];
-    }
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][0], bv[g][0], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][1], bv[g][1], acc2, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][2], bv[g][2], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][3], bv[g][3], acc2, 0, 0, 0);
-    }
-    {
-        constexpr int P = NG < 2 ? NG : 2;
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * P, 0);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            if (g + P < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        }
-    }
-    acc += acc2;
-    float mv[4], yv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        mv[r] = fmaxf(acc[r], mel_floor);
-        yv[r] = fmaf(__log2f(mv[r]), 0.25f * 0.30102999566398120f, y_bias);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(o_r[r]));
-    if (col_live) {
-        if (kMask && (tbits | mbits) != 0u) {                             // wave-uniform
-            const bool tmasked = (tbits >> (lane & 15)) & 1u;
-            const unsigned mb = (mbits >> ((lane >> 4) * 4)) & 15u;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                *reinterpret_cast<float*>(reinterpret_cast<char*>(out_u) + o_r[r]) = (tmasked || ((mb >> r) & 1u)) ? 0.0f : yv[r];
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(reinterpret_cast<char*>(out_u) + o_r[r]) = yv[r];
-        }
-    }
-    run_max = fmaxf(fmaxf(run_max, fmaxf(mv[0], mv[1])), fmaxf(mv[2], mv[3]));
-    tile_min = fminf(fminf(tile_min, fminf(mv[0], mv[1])), fminf(mv[2], mv[3]));
-}
-
-// SEQ: the two passes of a tile one after the other with the twiddles re-read from LDS per pass (fewer live registers:
-// the three-waves-per-SIMD build); otherwise interleaved as in whisper_stft_mel_kernel with the twiddles resident.
-template <int W, bool SEQ>
-__global__ __launch_bounds__(64 * W, W / 4) void whisper_stft_mel_wave_kernel(
-    const float* __restrict__ pcm, const int64_t* __restrict__ offsets,
-    const int32_t* __restrict__ lengths, int n_mels, int n_frames,
-    const WhisperTablesHeader* __restrict__ tab, float* __restrict__ out,
-    unsigned* __restrict__ keys, const int32_t* __restrict__ mask_tbl, int n_masks, int tiles_per_item,
-    int batch, unsigned* __restrict__ ticket, const float* __restrict__ clip_scale, int mode, float pad_value) {
-    using namespace wh;
-    using L = ww::Lds<W>;
-    constexpr int kThreadsW = L::kThreads;
-    constexpr int kWT = ww::kWTile;
-    __shared__ __attribute__((aligned(16))) float smem[L::kLdsFloats];
-
-    if (tab->magic != kWhisperMagic || tab->n_mels != n_mels) return;      // kernel 2 poisons the output
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int p = lane / 20;                 // pair within the wave (3 = idle lanes 60..63)
-    const int j = lane - p * 20;
-    const bool active = lane < 60;
-    const int pa_ = active ? p : 0;
-
-    const int n_tiles48 = (n_frames + kTileFrames - 1) / kTileFrames;
-    const int n_wtiles = (n_frames + kWT - 1) / kWT;
-    const int len_cap = mode == kModeTorchVarlen ? kVarMaxSamples : kMaxSamples;
-    auto clamp_len = [len_cap](int n) { return n < 0 ? 0 : (n > len_cap ? len_cap : n); };
-    auto first_pad_tile_of = [mode](int n_valid) {
-        return mode == kModeTorchVarlen ? (1 + n_valid / kHop + kTileFrames - 1) / kTileFrames
-                                        : (n_valid + kNfft / 2 + kHop * kTileFrames - 1) / (kHop * kTileFrames);
-    };
-    // first frame of a clip's constant region (what kernel 2 fills from) and the wave tiles in front of it
-    auto const_frame_of = [=](int n_valid) {
-        return whisper_const_frame(n_valid, n_frames, min(n_frames, min(n_tiles48, first_pad_tile_of(n_valid)) * kTileFrames), mode);
-    };
-    // (reference mode "padded": frame n_frames itself, the 3001st, counts for the per-clip maximum although it is cropped:
-    // clips that reach the end of the output get one more tile, of which only that frame is looked at)
-    auto wtiles_of = [=](int n_valid) {
-        const int cf = const_frame_of(n_valid);
-        return (mode == kModeTorchPadded && cf >= n_frames) ? (n_frames + kWT) / kWT : min(n_wtiles, (cf + kWT - 1) / kWT);
-    };
-
-    // ---- tables: every global load requested before the first LDS store
-    static_assert(sizeof(WhisperTablesHeader) % 16 == 0, "the mel weights behind the header are read as 16-byte words");
-    constexpr int kA = (kMaxAfragFloats / 4 + kThreadsW - 1) / kThreadsW;
-    f32x4 av[kA];
-    float wv, tv[2];
-    const int na4 = min(tab->afrag_floats, kMaxAfragFloats) >> 2;
-    {
-        const f32x4* __restrict__ afrag4 = reinterpret_cast<const f32x4*>(tab + 1);
-#pragma unroll
-        for (int k = 0; k < kA; ++k) av[k] = afrag4[min(tid + k * kThreadsW, na4 - 1)];
-        wv = tab->window[min(tid, 399)];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) tv[k] = tab->twiddle[min(tid + k * kThreadsW, 799)];
-    }
-    static_assert(kThreadsW >= 400 && 2 * kThreadsW >= 800, "one window value and two twiddle floats per thread");
-    // ---- clip lengths of the batch -> longest / shortest clip, wave tiles of the whole batch
-    int max_len = kMaxSamples, min_len = 0, sum_tiles = 0;
-    constexpr int kPer = (L::kMaxPlanClips + kThreadsW - 1) / kThreadsW;
-    const int per = (batch + kThreadsW - 1) / kThreadsW;
-    int lens[kPer];
-    if (batch <= L::kMaxPlanClips) {
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) lens[k] = clamp_len(lengths[min(tid * per + k, batch - 1)]);
-    }
-    if (batch <= 16384) {
-        int m = 0, mn = kMaxSamples, st = 0;
-        if (batch <= L::kMaxPlanClips) {
-#pragma unroll
-            for (int k = 0; k < kPer; ++k) {
-                if (k < per && tid * per + k < batch) {
-                    m = max(m, lens[k]);
-                    mn = min(mn, lens[k]);
-                    st += wtiles_of(lens[k]);
-                }
-            }
-        } else {
-            for (int i = tid; i < batch; i += kThreadsW) {
-                const int l = clamp_len(lengths[i]);
-                m = max(m, l);
-                mn = min(mn, l);
-                st += wtiles_of(l);
-            }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            m = max(m, __shfl_xor(m, off, 64));
-            mn = min(mn, __shfl_xor(mn, off, 64));
-            st += __shfl_xor(st, off, 64);
-        }
-        if (lane == 0) {
-            reinterpret_cast<int*>(smem)[wave] = m;
-            reinterpret_cast<int*>(smem)[W + wave] = mn;
-            reinterpret_cast<int*>(smem)[2 * W + wave] = st;
-        }
-        __syncthreads();
-        max_len = 0;
-        min_len = kMaxSamples;
-        for (int w = 0; w < W; ++w) {
-            max_len = max(max_len, reinterpret_cast<const int*>(smem)[w]);
-            min_len = min(min_len, reinterpret_cast<const int*>(smem)[W + w]);
-            sum_tiles += reinterpret_cast<const int*>(smem)[2 * W + w];
-        }
-        __syncthreads();
-    }
-    // Tiles per item: an item switch costs a wave a few hundred cycles (no barrier, the next item's PCM is already on
-    // its way), so items are short -- about sixteen per wave -- and the tail of the launch is one short item.
-    const int total_waves = (int)gridDim.x * W;
-    const int max_wt = wtiles_of(max_len);
-    if (tiles_per_item <= 0) {
-        tiles_per_item = sum_tiles > 0 ? sum_tiles / (16 * total_waves) : (max_wt + 49) / 50;
-        tiles_per_item = max(2, min(8, tiles_per_item));
-    }
-    tiles_per_item = __builtin_amdgcn_readfirstlane(tiles_per_item);
-    const int n_runs = (max_wt + tiles_per_item - 1) / tiles_per_item;
-    auto runs_of = [&](int n_valid) { return (wtiles_of(n_valid) + tiles_per_item - 1) / tiles_per_item; };
-    int* plan = reinterpret_cast<int*>(smem + L::kPlanOff);
-    const bool planned = __builtin_amdgcn_readfirstlane(
-        (batch <= L::kMaxPlanClips && batch <= 16384 && runs_of(min_len) != n_runs) ? 1 : 0);
-    int n_items = n_runs * batch;
-    if (planned) {
-        int before[kPer], sum = 0;
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const int c = tid * per + k;
-            before[k] = sum;
-            if (k < per && c < batch) sum += runs_of(lens[k]);
-        }
-        int incl = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
-        if (lane == 63) reinterpret_cast<int*>(smem)[wave] = incl;
-        __syncthreads();
-        int base = incl - sum;
-        for (int w = 0; w < wave; ++w) base += reinterpret_cast<const int*>(smem)[w];
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const int c = tid * per + k;
-            if (k < per && c < batch) plan[c] = base + before[k];
-        }
-        if (tid == kThreadsW - 1) plan[batch] = base + sum;
-        __syncthreads();
-        n_items = plan[batch];
-    }
-    auto decode = [&](int it, int& clip_out, int& run_out) {
-        if (planned) {
-            const int stride = (batch + 63) >> 6;
-            const int c1 = lane * stride;
-            const bool le1 = c1 < batch && plan[min(c1, batch)] <= it;
-            const int block = __popcll(__ballot(le1)) - 1;
-            const int c2 = block * stride + lane;
-            const bool le2 = lane < stride && c2 < batch && plan[min(c2, batch)] <= it;
-            const int c = block * stride + __popcll(__ballot(le2)) - 1;
-            clip_out = __builtin_amdgcn_readfirstlane(c);
-            run_out = __builtin_amdgcn_readfirstlane(it - plan[c]);
-        } else {
-            run_out = __builtin_amdgcn_readfirstlane(it / batch);
-            clip_out = __builtin_amdgcn_readfirstlane(it - run_out * batch);
-        }
-    };
-
-    // ---- zero the slabs (pad cells are read by zero-weight MFMA steps and must be finite), stage the tables
-    {
-        for (int i = tid; i < L::kWinOff; i += kThreadsW) smem[i] = 0.f;
-        if (tid < 400) smem[L::kWinOff + (tid % 20) * 20 + tid / 20] = wv;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int i = tid + k * kThreadsW;
-            const int c = i >> 1, k1 = c / 20, jj = c - 20 * k1;
-            if (i < 800) smem[L::kTwOff + jj * kTwStride + 2 * k1 + (i & 1)] = tv[k];
-        }
-#pragma unroll
-        for (int k = 0; k < kA; ++k) {
-            const int i = tid + k * kThreadsW;
-            if (i < na4) reinterpret_cast<f32x4*>(smem + L::kAfragOff)[i] = av[k];
-        }
-    }
-    __syncthreads();
-    // ===== from here on the waves are on their own =====
-    const int gw = (int)blockIdx.x * W + wave;
-    int item = gw;
-    if (item >= n_items) return;
-    int next_item = min(gw + total_waves, n_items);
-    int clip_cur, run_cur, clip_nx = 0, run_nx = 0;
-    decode(item, clip_cur, run_cur);
-    if (next_item < n_items) decode(next_item, clip_nx, run_nx);
-    int len_cur = lengths[clip_cur];
-    int64_t off_cur = offsets[clip_cur];
-    int len_next = 0;
-    int64_t off_next = 0;
-    unsigned my_ticket = 0;
-
-    auto load_pass = [&](const float* __restrict__ x, int n_valid, int t0, int pass, float (&r)[28]) {
-        const int f0 = t0 + 6 * pass;                                  // first frame of the pass (wave-uniform)
-        const int first = kHop * f0 - kNfft / 2;
-        const int base = first + 2 * kHop * pa_ + j;
-        if (first >= 0 && first + 5 * kHop + kNfft <= n_valid) {
-#pragma unroll
-            for (int m = 0; m < 28; ++m) r[m] = x[base + 20 * m];
-        } else if (mode != kModeTorchVarlen && first >= n_valid && first + 5 * kHop + kNfft <= kMaxSamples) {
-#pragma unroll
-            for (int m = 0; m < 28; ++m) r[m] = 0.0f;
-        } else {
-#pragma unroll
-            for (int m = 0; m < 28; ++m) {
-                int idx = base + 20 * m;
-                const int lim = mode == kModeTorchVarlen ? n_valid : kMaxSamples;
-                idx = idx < 0 ? -idx : idx;
-                idx = idx >= lim ? 2 * (lim - 1) - idx : idx;
-                r[m] = (idx >= 0 && idx < n_valid) ? x[idx] : 0.0f;
-            }
-        }
-    };
-    float raw0[28], raw1[28];
-    bool raw_ready = false;
-
-    const float* afrag = smem + L::kAfragOff;
-    const int partner = active ? (p * 20 + ((20 - j) % 20)) : lane;
-    float* my_rows = smem + wave * kSlabFloats;
-    f2* slab_w = reinterpret_cast<f2*>(my_rows) + pa_ * kPairStride + j;
-    const f32x4* slab_r = reinterpret_cast<const f32x4*>(my_rows + 2 * (pa_ * kPairStride + j * kRowStride));
-    const f32x4* win4 = reinterpret_cast<const f32x4*>(smem + L::kWinOff + 20 * j);
-    const f32x4* tw4 = reinterpret_cast<const f32x4*>(smem + L::kTwOff + kTwStride * j);
-    f32x4 t4g[10];
-    if constexpr (!SEQ) {
-#pragma unroll
-        for (int q = 0; q < 10; ++q) t4g[q] = tw4[q];
-    }
-
-    auto s1_math = [&](const float (&raw)[28], f2 (&y)[20]) {
-        f2 v[20];
-        f32x4 w4[5];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) w4[q] = win4[q];
-        f32x4 t4l[10];                                                 // SEQ: twiddles re-read per pass
-        if constexpr (SEQ) {
-#pragma unroll
-            for (int q = 0; q < 10; ++q) t4l[q] = tw4[q];
-        }
-#pragma unroll
-        for (int i = 0; i < 20; ++i) {
-            const float w = w4[i >> 2][i & 3];
-            v[i] = f2{raw[i] * w, raw[i + 8] * w};
-        }
-        dft20_pk(v, y);
-#pragma unroll
-        for (int k1 = 1; k1 < 20; ++k1) {
-            const f32x4 tq = SEQ ? t4l[k1 >> 1] : t4g[k1 >> 1];
-            const f2 tw = {tq[2 * (k1 & 1)], tq[2 * (k1 & 1) + 1]};
-            y[k1] = cmul_pk(y[k1], tw);
-        }
-    };
-    auto s1_write = [&](const f2 (&y)[20]) {
-        wave_lds_sync();
-        if (active) {
-#pragma unroll
-            for (int k1 = 0; k1 < 20; ++k1) slab_w[k1 * kRowStride] = y[k1];
-        }
-        wave_lds_sync();
-    };
-    auto s2_read = [&](f32x4 (&r4)[10]) {
-#pragma unroll
-        for (int q = 0; q < 10; ++q) r4[q] = slab_r[q];
-    };
-    auto s2_math = [&](const f32x4 (&r4)[10], f2 (&y)[20]) {
-        f2 v[20];
-#pragma unroll
-        for (int q = 0; q < 10; ++q) {
-            v[2 * q] = f2{r4[q][0], r4[q][1]};
-            v[2 * q + 1] = f2{r4[q][2], r4[q][3]};
-        }
-        dft20_pk(v, y);
-    };
-    auto sep_fetch = [&](const f2 (&y)[20], f2 (&q)[10]) {
-#pragma unroll
-        for (int k2 = 0; k2 < 10; ++k2)
-            q[k2] = f2{__shfl(y[19 - k2].x, partner, 64), __shfl(y[19 - k2].y, partner, 64)};
-    };
-    auto sep_math = [&](const f2 (&y)[20], const f2 (&q)[10], f2 (&pw)[11]) {
-#pragma unroll
-        for (int k2 = 0; k2 < 10; ++k2) {
-            const f2 qq = (j == 0) ? ((k2 == 0) ? y[0] : y[20 - k2]) : q[k2];
-            pw[k2] = power_pair(y[k2] + qq, y[k2] - qq);
-        }
-        pw[10] = y[10] * y[10] * 4.0f;
-    };
-    auto store_rows = [&](int pass, const f2 (&pw)[11]) {
-        if (!active) return;
-        float* row = my_rows + (6 * pass + 2 * p) * kPStride + j;
-#pragma unroll
-        for (int k2 = 0; k2 < 10; ++k2) {
-            row[20 * k2] = pw[k2].x;
-            row[kPStride + 20 * k2] = pw[k2].y;
-        }
-        if (j == 0) {
-            row[200] = pw[10].x;
-            row[kPStride + 200] = pw[10].y;
-        }
-    };
-
-    // B operand of this lane: panel row of frame min(lane & 15, 11), bins 4 (lane >> 4) + ...
-    const int fcol = lane & 15;
-    const bool col_live = fcol < kWT;
-    const int frow = col_live ? fcol : fcol - kWT;                    // columns 12..15 repeat frames 0..3
-    const float* b_lane = my_rows + frow * kPStride + 4 * (lane >> 4);
-    const int static_plan = __builtin_amdgcn_readfirstlane(
-        n_mels == 80 && plan_matches<80>(tab->plan) ? 80 : (n_mels == 128 && plan_matches<128>(tab->plan) ? 128 : 0));
-    const int n_mtiles = __builtin_amdgcn_readfirstlane(tab->plan.n_mtiles);
-    const float* a_lane = smem + L::kAfragOff + 4 * lane;
-    unsigned o_r[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o_r[r] = 4u * (unsigned)(((lane >> 4) * 4 + r) * n_frames + fcol);
-    int32_t* clip_masks = reinterpret_cast<int32_t*>(smem + L::kMaskOff) + wave * 3 * STTFE_MAX_MASKS;
-    const int nm = mask_tbl ? n_masks : 0;
-#ifdef STTFE_STAMPS
-    // slots 0: top of tile -> FFT done; 1: panel rows; 2: PCM requests; 3: mel phase; 4: tile min + atomic; 5: item switch
-    unsigned long long stamp_sum[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
-    const unsigned long long stamp_entry = stamp_prev;
-#endif
-
-    while (item < n_items) {
-        const int run = run_cur, clip = clip_cur;
-        const int n_valid = clamp_len(__builtin_amdgcn_readfirstlane(len_cur));
-        const int64_t off_x = ((int64_t)__builtin_amdgcn_readfirstlane((int)(off_cur >> 32)) << 32) |
-                              (uint32_t)__builtin_amdgcn_readfirstlane((int)off_cur);
-        const float* __restrict__ x = pcm + off_x;
-        float mel_floor = 1e-10f, y_bias = 1.0f;
-        if (clip_scale) {
-            const float sc = clip_scale[clip];
-            mel_floor = 1e-10f / (sc * sc);
-            y_bias = 1.0f + 0.5f * 0.30102999566398120f * __log2f(sc);
-        }
-        if (lane == 0 && next_item < n_items) my_ticket = atomicInc(ticket, 0xffffffffu);   // -> the item after the next
-        if (next_item < n_items) {
-            len_next = lengths[clip_nx];
-            off_next = offsets[clip_nx];
-        }
-        const int wt_begin = run * tiles_per_item;
-        const int wt_end = min(wt_begin + tiles_per_item, wtiles_of(n_valid));
-        unsigned ticket_val = 0xffffffffu;
-        const int key_frames = mode == kModeTorchVarlen ? 1 + n_valid / kHop : (mode == kModeTorchPadded ? n_frames + 1 : n_frames);
-        const int const_frame = const_frame_of(n_valid);
-        if (wt_begin < wt_end) {
-            float* __restrict__ out_clip = out + (size_t)clip * n_mels * n_frames;
-            if (nm > 0) {
-                wave_lds_sync();
-                if (lane < 3 * nm) clip_masks[lane] = mask_tbl[(size_t)clip * n_masks * 3 + lane];
-                wave_lds_sync();
-            }
-            const uint64_t melmask_lo = mask_bits(clip_masks, nm, STTFE_AXIS_FREQ, 0, 64);
-            const uint64_t melmask_hi = mask_bits(clip_masks, nm, STTFE_AXIS_FREQ, 64, 64);
-            if (!raw_ready) {
-                load_pass(x, n_valid, wt_begin * kWT, 0, raw0);
-                load_pass(x, n_valid, wt_begin * kWT, 1, raw1);
-            }
-            raw_ready = false;
-            float run_max = 0.0f;
-            for (int wt = wt_begin; wt < wt_end; ++wt) {
-                const int t0 = wt * kWT;
-                STAMP(5);
-                f2 pw0[11], pw1[11];
-                {
-                  if constexpr (SEQ) {
-                    {
-                        f2 ya[20], q0[10];
-                        f32x4 ra[10];
-                        s1_math(raw0, ya);
-                        s1_write(ya);
-                        s2_read(ra);
-                        s2_math(ra, ya);
-                        sep_fetch(ya, q0);
-                        sep_math(ya, q0, pw0);
-                    }
-                    {
-                        f2 yb[20], q1[10];
-                        f32x4 rb[10];
-                        s1_math(raw1, yb);
-                        s1_write(yb);
-                        s2_read(rb);
-                        s2_math(rb, yb);
-                        sep_fetch(yb, q1);
-                        sep_math(yb, q1, pw1);
-                    }
-                  } else {
-                    f2 ya[20], yb[20], q0[10], q1[10];
-                    f32x4 ra[10], rb[10];
-                    s1_math(raw0, ya);
-                    s1_write(ya);
-                    s2_read(ra);
-                    s1_math(raw1, yb);
-                    s1_write(yb);
-                    s2_read(rb);
-                    s2_math(ra, ya);
-                    sep_fetch(ya, q0);
-                    s2_math(rb, yb);
-                    sep_fetch(yb, q1);
-                    sep_math(ya, q0, pw0);
-                    sep_math(yb, q1, pw1);
-                  }
-                }
-                STAMP(0);
-                wave_lds_sync();
-                store_rows(0, pw0);
-                store_rows(1, pw1);
-                STAMP(1);
-                // next tile's PCM (of this item, or the first tile of the wave's next item): lands under the mel phase
-                if (wt + 1 < wt_end) {
-                    load_pass(x, n_valid, t0 + kWT, 0, raw0);
-                    load_pass(x, n_valid, t0 + kWT, 1, raw1);
-                } else if (next_item < n_items) {
-                    // the ticket taken at the top of this item is read HERE, in front of the prefetch: behind it the wait
-                    // for the atomic's value would also wait for these 56 loads
-                    ticket_val = (unsigned)__builtin_amdgcn_readfirstlane((int)my_ticket);
-                    int nv = clamp_len(__builtin_amdgcn_readfirstlane(len_next)), tb = __builtin_amdgcn_readfirstlane(run_nx * tiles_per_item);
-                    asm volatile("" : "+v"(nv), "+v"(tb));
-                    nv = __builtin_amdgcn_readfirstlane(nv);
-                    tb = __builtin_amdgcn_readfirstlane(tb);
-                    const int64_t off_n = ((int64_t)__builtin_amdgcn_readfirstlane((int)(off_next >> 32)) << 32) |
-                                          (uint32_t)__builtin_amdgcn_readfirstlane((int)off_next);
-                    if (tb < wtiles_of(nv)) {
-                        load_pass(pcm + off_n, nv, tb * kWT, 0, raw0);
-                        load_pass(pcm + off_n, nv, tb * kWT, 1, raw1);
-                        raw_ready = true;
-                    }
-                }
-                STAMP(2);
-                wave_lds_sync();                                       // this wave's panel rows are in place
-
-                // ---------------- all mel tiles of these 12 frames on the matrix cores + log epilogue --------------
-                const unsigned tmask = (unsigned)mask_bits(clip_masks, nm, STTFE_AXIS_TIME, t0, kWT);
-                float tile_min = 3.0e38f;
-                float* __restrict__ ob = out_clip + t0;
-                const size_t nf16 = (size_t)16 * n_frames;
-                if (static_plan != 0 && t0 + kWT <= min(min(n_frames, key_frames), const_frame)) {
-#define STTFE_UW(NM, MT)                                                                                              \
-    mel_unit_wave<NM, MT, STTFE_MASKED>(a_lane, b_lane, ob + MT * nf16, o_r, mel_floor, y_bias, run_max, tile_min, tmask, \
-                                        (unsigned)((MT < 4 ? melmask_lo : melmask_hi) >> ((MT & 3) * 16)) & 0xffffu, lane, col_live)
-                    if (nm == 0) {
-#define STTFE_MASKED false
-                        if (static_plan == 80) {
-                            STTFE_UW(80, 4); STTFE_UW(80, 3); STTFE_UW(80, 2); STTFE_UW(80, 1); STTFE_UW(80, 0);
-                        } else {
-                            STTFE_UW(128, 7); STTFE_UW(128, 6); STTFE_UW(128, 5); STTFE_UW(128, 4);
-                            STTFE_UW(128, 3); STTFE_UW(128, 2); STTFE_UW(128, 1); STTFE_UW(128, 0);
-                        }
-#undef STTFE_MASKED
-                    } else {
-#define STTFE_MASKED true
-                        if (static_plan == 80) {
-                            STTFE_UW(80, 4); STTFE_UW(80, 3); STTFE_UW(80, 2); STTFE_UW(80, 1); STTFE_UW(80, 0);
-                        } else {
-                            STTFE_UW(128, 7); STTFE_UW(128, 6); STTFE_UW(128, 5); STTFE_UW(128, 4);
-                            STTFE_UW(128, 3); STTFE_UW(128, 2); STTFE_UW(128, 1); STTFE_UW(128, 0);
-                        }
-#undef STTFE_MASKED
-                    }
-#undef STTFE_UW
-                } else {
-                    // generic: any n_mels, partial tiles (clip / output ends), the plan's bands from the tables
-                    for (int mt = 0; mt < n_mtiles; ++mt) {
-                        const int ks = __builtin_amdgcn_readfirstlane(tab->plan.kstart[mt]);
-                        const int ng = __builtin_amdgcn_readfirstlane(tab->plan.nsteps[mt]) >> 2;
-                        const int ao = __builtin_amdgcn_readfirstlane(tab->plan.aoff[mt]);
-                        const f32x4* a_ptr = reinterpret_cast<const f32x4*>(afrag + ao) + lane;
-                        const f32x4* b_ptr = reinterpret_cast<const f32x4*>(b_lane + ks);
-                        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-                        for (int g = 0; g < ng; ++g) {
-                            const f32x4 an = a_ptr[g * 64], bn = b_ptr[4 * g];
-                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(an[0], bn[0], acc, 0, 0, 0);
-                            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(an[1], bn[1], acc2, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(an[2], bn[2], acc, 0, 0, 0);
-                            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(an[3], bn[3], acc2, 0, 0, 0);
-                        }
-                        acc += acc2;
-                        const int mel0 = mt * 16 + (lane >> 4) * 4;
-                        const int fr = t0 + fcol;                                      // live columns only below
-                        const unsigned o0 = (unsigned)(mel0 * n_frames + fr);
-                        const bool tmasked = (tmask >> fcol) & 1u;
-                        const unsigned mbits = (unsigned)((mel0 < 64 ? melmask_lo >> mel0 : melmask_hi >> (mel0 - 64)) & 15ull);
-                        const bool counted = col_live && fr < key_frames, stored = col_live && fr < n_frames, varies = fr < const_frame;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float mv = fmaxf(acc[r], mel_floor);
-                            const float yv = fmaf(__log2f(mv), 0.25f * 0.30102999566398120f, y_bias);
-                            if (mel0 + r < n_mels) {
-                                if (counted) {
-                                    run_max = fmaxf(run_max, mv);
-                                    if (varies) tile_min = fminf(tile_min, mv);
-                                }
-                                if (stored)
-                                    out_clip[o0 + (unsigned)(r * n_frames)] =
-                                        (tmasked || ((mbits >> r) & 1u)) ? 0.0f : (counted ? yv : pad_value);
-                            }
-                        }
-                    }
-                }
-                STAMP(3);
-                tile_min = wave_min(tile_min);
-                if (lane == 0 && tile_min < 1.0e38f)
-                    atomicMax(&keys[(size_t)clip * kKeysPerClip + 1 + wt / ww::kWTilesPerKeyTile],
-                              ~float_to_key(__log2f(tile_min) * 0.30102999566398120f));
-                wave_lds_sync();                                       // panel reads before the next tile's slab writes
-                STAMP(4);
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) run_max = fmaxf(run_max, __shfl_xor(run_max, off, 64));
-            if (lane == 0 && run_max > 0.0f)
-                atomicMax(&keys[(size_t)clip * kKeysPerClip], float_to_key(__log2f(run_max) * 0.30102999566398120f));
-        }
-        if (next_item < n_items && ticket_val == 0xffffffffu) ticket_val = (unsigned)__builtin_amdgcn_readfirstlane((int)my_ticket);
-        const int after_next = (next_item < n_items)
-                                   ? (int)min((unsigned long long)ticket_val + 2ull * (unsigned)total_waves, (unsigned long long)n_items)
-                                   : n_items;
-        item = next_item;
-        clip_cur = clip_nx;
-        run_cur = run_nx;
-        next_item = after_next;
-        if (next_item < n_items) decode(next_item, clip_nx, run_nx);
-        len_cur = len_next;
-        off_cur = off_next;
-    }
-#ifdef STTFE_STAMPS
-    if (g_stamp_buf && lane == 0) {
-        STAMP(6);
-        stamp_sum[13] = stamp_entry;
-        stamp_sum[14] = stamp_prev;
-        unsigned long long* dst = g_stamp_buf + ((size_t)blockIdx.x * W + wave) * 20;
-        for (int i = 0; i < 20; ++i) dst[i] = stamp_sum[i];
-    }
-#endif
-}
-
 // Clamp / fill pass.  grid.x = row split, grid.y = clips: workgroup x owns mel rows x, x + gridDim.x, ... of its clip.
 //   fill : the clip's zero-padding region [first padding frame, n_frames) gets the final constant with full-row
 //          vector stores (kernel 1 never touches it);
@@ -1712,7 +1019,11 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
                 const float c = mmasked ? 0.0f : pad_y;
                 *reinterpret_cast<f32x4*>(a) = f32x4{c, c, c, c};
             } else if ((a < start && a >= clip_base + (size_t)mel * n_frames * 4) ||
-                       (a >= end && a < ((end + 127) & ~(uintptr_t)127) && r + 1 < rows)) {
+                       (a >= end && a < ((end + 127) & ~(uintptr_t)127) && r + 1 < rows &&
+                        a < end + (size_t)pad_frame * 4)) {
+                // (the tail of a row's last line is kept only where it holds COMPUTED frames of this workgroup's next
+                // row: with short clips or short rows -- pad_frame * 4 < 128 bytes, compact n_frames < 32 -- the line
+                // reaches that row's own fill segment, which its fill lane writes, or rows of another workgroup)
                 const f32x4 keep = *reinterpret_cast<const f32x4*>(a);          // computed cells of this workgroup's rows
                 *reinterpret_cast<f32x4*>(a) = keep;
             }
@@ -1864,28 +1175,7 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
     const long most_items = (long)batch * ((n_tiles + 2) / 3);      // fewer workgroups than that cannot all find work
     const int grid = most_items < resident ? (int)most_items : resident;
     const auto* tab = reinterpret_cast<const WhisperTablesHeader*>(dev_tables);
-    static const int wave_form = [] {                             // 0: workgroup tiles (round 2), 8 / 12: wave-independent
-        const char* e = getenv("STTFE_WH_KERNEL");
-        const int v = e ? atoi(e) : STTFE_WH_DEFAULT_FORM;
-        return (v == 8 || v == 12) ? v : 0;
-    }();
-    if (wave_form != 0) {
-        ScopedTiming t(kTimeWhisperStftMel, stream);
-        const int n_wtiles = (n_frames + ww::kWTile - 1) / ww::kWTile;
-        const long most_items = ((long)batch * n_wtiles + 1) / 2;          // items are at least two tiles long
-        const long wgs = (most_items + wave_form - 1) / wave_form;
-        const int cus = current_device_cus();
-        const int grid_w = wgs < cus ? (int)wgs : cus;
-        const int tpi = tiles_per_block * ww::kWTilesPerKeyTile;          // the knob counts 48-frame tiles
-        if (wave_form == 12)
-            hipLaunchKernelGGL((whisper_stft_mel_wave_kernel<12, true>), dim3(grid_w), dim3(768), 0, stream,
-                               pcm, offsets, lengths, n_mels, n_frames, tab, out, keys, mask_tbl, n_masks, tpi,
-                               batch, keys + (size_t)batch * wh::kKeysPerClip, clip_scale, mode, pad_value);
-        else
-            hipLaunchKernelGGL((whisper_stft_mel_wave_kernel<8, false>), dim3(grid_w), dim3(512), 0, stream,
-                               pcm, offsets, lengths, n_mels, n_frames, tab, out, keys, mask_tbl, n_masks, tpi,
-                               batch, keys + (size_t)batch * wh::kKeysPerClip, clip_scale, mode, pad_value);
-    } else {
+    {
         ScopedTiming t(kTimeWhisperStftMel, stream);
 #ifdef STTFE_STAMPS
         // diagnostic build: extra dynamic LDS forces one workgroup per CU (phase times without a co-resident workgroup)

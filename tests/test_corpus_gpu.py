@@ -132,3 +132,31 @@ def test_compact_frames_rule_and_argument_checks(corpus):
         ref = fe.extract(pcm2d.reshape(-1), offsets[:2], ln)
         got = fe.extract(pcm2d.reshape(-1), offsets[:2], ln, n_frames=T)
         assert torch.equal(got, ref[:, :, :T]) and bool((ref[:, :, T:] == got[:, :, -1:]).all()), n
+
+
+@pytest.mark.parametrize("n_frames", [8, 28, 200, 500, 3000])
+def test_short_loud_clips_compact_and_full_against_the_oracle(n_frames):
+    """ADVICE r2 (fill pass of the clamp / fill kernel): clips of a few hundred samples have pad_frame * 4 < 128 bytes,
+    and compact rows of fewer than 32 frames put several mel rows into one 128-byte line -- the lanes that complete a
+    row's last line must not touch the fill segment of the next row or rows of another workgroup.  Loud clips make the
+    clamp floor (max - 8) differ from the unclamped -1.5 kernel 1 leaves behind, so a stale cell shows.  Checked against
+    the ORACLE (not against the same kernel), several times over: a race would not show on every run."""
+    from oracle.whisper import whisper_features
+    from speech_to_text_amd.processors import HipWhisperFeatureExtractor
+    fe = HipWhisperFeatureExtractor(80, device=DEV)
+    rng = np.random.default_rng(77)
+    sizes = [0, 37, 199, 200, 201, 333, 440, 441, 600, 999, 1000, 160 * (n_frames - 4) - 200 if n_frames < 3000 else 4000]
+    sizes = [min(max(n, 0), max(160 * (n_frames - 4) - 200, 0)) for n in sizes]
+    clips = [(0.9 * rng.standard_normal(n)).astype(np.float32).clip(-1, 1) for n in sizes]
+    exp = whisper_features(clips, 80)[:, :, :n_frames]
+    n_max = 4096 if n_frames == 3000 else max(max(sizes), 64)
+    n_max = (n_max + 63) // 64 * 64
+    pcm = torch.zeros((len(clips), n_max), dtype=torch.float32, device=DEV)
+    for i, c in enumerate(clips):
+        pcm[i, :len(c)] = torch.from_numpy(c)
+    offsets = (torch.arange(len(clips), dtype=torch.int64) * n_max).to(DEV)
+    lengths = torch.tensor(sizes, dtype=torch.int32, device=DEV)
+    for _ in range(5):
+        got = fe.extract(pcm.reshape(-1), offsets, lengths, n_frames=n_frames).cpu().numpy()
+        assert got.shape == exp.shape
+        assert float(np.abs(got - exp).max()) <= 1e-4
