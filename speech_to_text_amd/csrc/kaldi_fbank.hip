@@ -1108,163 +1108,6 @@ __global__ __launch_bounds__(256) void kaldi_cmvn_seq_kernel(
     }
 }
 
-// float64 mode, streaming form (round 3; the default for shapes it takes): ONE workgroup per clip, whole rows.
-// kaldi_cmvn_seq_kernel gives a workgroup 8 columns of a clip: 32-byte pieces of every output row, read and written by
-// ten workgroups at ten different times -- 135 MB of write traffic for 66 MB of output on config 2 (partly written lines
-// leave L2 before their neighbours arrive) -- and its load, chain and store phases run one after the other, chip-wide,
-// because all workgroups start together.  Here a workgroup streams its clip's rows (n_mels floats, whole 128-byte
-// lines) through a two-chunk LDS ring four times: three times for the three NumPy-order float32 sums (lane = column:
-// threads 0 .. n_mels - 1 each carry one column's chain, same additions in the same order as kaldi_stats_seq_kernel),
-// with all 256 threads fetching the chunks two ahead, and once to normalise.  The re-reads are L2 / Infinity Cache
-// hits (the clip's raw log-mel was written by kaldi_fbank64_kernel just before); every output line is written once,
-// whole.
-namespace cmvn_stream {
-constexpr int kRows = 64;                 // rows per chunk
-constexpr int kMaxQuads = 8;              // float4 per thread and chunk: 64 rows x 128 bins / 4 / 256 threads
-}  // namespace cmvn_stream
-__global__ __launch_bounds__(256) void kaldi_cmvn_stream_kernel(
-    float* __restrict__ out, const int32_t* __restrict__ lengths, int batch, int n_mels, int t_max, int max_frames,
-    void* __restrict__ attn, int attn_bytes, const int32_t* __restrict__ mask_tbl, int n_masks,
-    const KaldiTablesHeader* __restrict__ tab) {
-#pragma clang fp contract(off)
-    using namespace cmvn_stream;
-    extern __shared__ __attribute__((aligned(16))) float ring[];       // [2][kRows][n_mels]
-    __shared__ float s_mean[128], s_std[128];
-    const int tid = threadIdx.x, clip = blockIdx.x;
-    float* __restrict__ o = out + (size_t)clip * t_max * n_mels;
-    const int row_quads = n_mels >> 2;                                  // float4 per row (n_mels % 4 == 0)
-    if (tab->magic != kKaldiMagic || tab->n_mels != n_mels) {
-        for (int i = tid; i < t_max * n_mels; i += 256) o[i] = __builtin_nanf("");
-        return;
-    }
-    const int T = kaldi_num_frames(lengths[clip], max_frames, t_max);
-    const int chunk_quads = kRows * row_quads;                          // float4 per full chunk
-    const int total_quads = T * row_quads;
-    const int n_chunks = (T + kRows - 1) / kRows;
-    const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(o);
-    f32x4* ring4 = reinterpret_cast<f32x4*>(ring);
-    auto fetch = [&](f32x4 (&r)[kMaxQuads], int chunk) {               // chunk's quads -> registers (clamped: no branch)
-        const int base = chunk * chunk_quads;
-#pragma unroll
-        for (int k = 0; k < kMaxQuads; ++k) {
-            const int i = tid + 256 * k;
-            if (i < chunk_quads) r[k] = src[min(base + i, max(total_quads - 1, 0))];
-        }
-    };
-    auto deposit = [&](const f32x4 (&r)[kMaxQuads], int slot) {
-#pragma unroll
-        for (int k = 0; k < kMaxQuads; ++k) {
-            const int i = tid + 256 * k;
-            if (i < chunk_quads) ring4[slot * chunk_quads + i] = r[k];
-        }
-    };
-    const bool chain = tid < n_mels;
-    // one pass over the clip: acc = (((term(x[0]) + term(x[1])) + ...) + term(x[T - 1])) per column, float32
-    auto sweep = [&](auto&& term) {
-        float acc = 0.0f;
-        if (T == 0) return acc;                                         // workgroup-uniform
-        f32x4 ra[kMaxQuads], rb[kMaxQuads];
-        fetch(ra, 0);
-        if (n_chunks > 1) fetch(rb, 1);
-        deposit(ra, 0);
-        if (n_chunks > 2) fetch(ra, 2);
-        __syncthreads();
-        for (int c = 0; c < n_chunks; ++c) {
-            // next chunk into the other slot (its last readers passed the barrier that ended the previous trip), then
-            // the chunk after next into the registers that just became free
-            if (c + 1 < n_chunks) {
-                if (c & 1) {
-                    deposit(ra, (c + 1) & 1);
-                    if (c + 3 < n_chunks) fetch(ra, c + 3);
-                } else {
-                    deposit(rb, (c + 1) & 1);
-                    if (c + 3 < n_chunks) fetch(rb, c + 3);
-                }
-            }
-            if (chain) {
-                const float* col = ring + (c & 1) * kRows * n_mels + tid;
-                const int rows = min(kRows, T - c * kRows);
-                int t = 0;
-                for (; t + 32 <= rows; t += 32) {
-                    float v[32];
-#pragma unroll
-                    for (int i = 0; i < 32; ++i) v[i] = term(col[(t + i) * n_mels]);
-#pragma unroll
-                    for (int i = 0; i < 32; ++i) acc = acc + v[i];
-                }
-                for (; t < rows; ++t) acc = acc + term(col[t * n_mels]);
-            }
-            __syncthreads();
-        }
-        return acc;
-    };
-    {
-        float mean = 0.0f, sd = 1.0f;
-        const float fT = (float)T;
-        const float s1 = sweep([](float x) { return x; });
-        if (T > 0) mean = s1 / fT;                                                          // x.mean(axis=0)
-        const float s2 = sweep([mean](float x) { return x - mean; });
-        const float arrmean = T > 0 ? s2 / fT : 0.0f;                                       // _var: mean of x - mean
-        const float ssq = sweep([mean, arrmean](float x) {
-            const float d = (x - mean) - arrmean;
-            return d * d;
-        });
-        if (T > 0) sd = sqrtf(ssq / fT);
-        if (chain) {
-            s_mean[tid] = mean;
-            s_std[tid] = sd;
-        }
-    }
-    __syncthreads();
-    int m_axis[STTFE_MAX_MASKS], m_s[STTFE_MAX_MASKS], m_e[STTFE_MAX_MASKS];
-    const int nm = mask_tbl ? (n_masks > STTFE_MAX_MASKS ? STTFE_MAX_MASKS : n_masks) : 0;
-    for (int i = 0; i < nm; ++i) {
-        const int32_t* m = mask_tbl + ((size_t)clip * n_masks + i) * 3;
-        m_axis[i] = m[0];
-        m_s[i] = m[1];
-        m_e[i] = m[2];
-    }
-    auto norm = [&](float x, int t, int c) {
-        float y = (x - s_mean[c]) / s_std[c];
-        for (int i = 0; i < nm; ++i) {
-            const int idx = (m_axis[i] == STTFE_AXIS_TIME) ? t : c;
-            if (idx >= m_s[i] && idx < m_e[i]) y = 0.0f;
-        }
-        return y;
-    };
-    // normalise in place, whole rows; eight loads in flight per thread before the first store
-    const int all_quads = t_max * row_quads;
-    f32x4* dst = reinterpret_cast<f32x4*>(o);
-    for (int base = tid; base < all_quads; base += 8 * 256) {
-        f32x4 r[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = base + 256 * k;
-            r[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (i < total_quads) r[k] = src[i];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = base + 256 * k;
-            if (i >= all_quads) continue;
-            if (i < total_quads) {
-                const int t = i / row_quads, c = (i - t * row_quads) * 4;
-                r[k][0] = norm(r[k][0], t, c);
-                r[k][1] = norm(r[k][1], t, c + 1);
-                r[k][2] = norm(r[k][2], t, c + 2);
-                r[k][3] = norm(r[k][3], t, c + 3);
-            }
-            dst[i] = r[k];
-        }
-    }
-    if (attn) {
-        for (int t = tid; t < t_max; t += 256) {
-            if (attn_bytes == 8) reinterpret_cast<int64_t*>(attn)[(size_t)clip * t_max + t] = t < T ? 1 : 0;
-            else reinterpret_cast<int32_t*>(attn)[(size_t)clip * t_max + t] = t < T ? 1 : 0;
-        }
-    }
-}
-
 }  // namespace sttfe
 
 using namespace sttfe;
@@ -1339,19 +1182,8 @@ extern "C" int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, 
         const bool seq_split = getenv("STTFE_KALDI_SPLIT_CMVN") != nullptr;     // A/B and test knob: the two-kernel form
         const size_t panel_bytes = (size_t)t_max * kG * sizeof(float);
         const bool f64_cmvn = (flags & STTFE_KALDI_F64) && !(flags & STTFE_KALDI_NO_CMVN);
-        // form of the float64-mode CMVN: 0 / unset = automatic (streaming form, one workgroup per clip), 1 = column
-        // groups (kaldi_cmvn_seq_kernel, round 2), 2 = the two-kernel form (as STTFE_KALDI_SPLIT_CMVN)
-        static const int cmvn_form = [] {
-            const char* e = getenv("STTFE_KALDI_CMVN_FORM");
-            const int v = e ? atoi(e) : 0;
-            return v < 0 || v > 2 ? 0 : v;
-        }();
-        if (f64_cmvn && !seq_split && cmvn_form == 0 && n_mels % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
-            const size_t ring_bytes = (size_t)2 * cmvn_stream::kRows * n_mels * sizeof(float);
-            hipLaunchKernelGGL(kaldi_cmvn_stream_kernel, dim3(batch), dim3(256), ring_bytes, stream, out, lengths, batch,
-                               n_mels, t_max, max_frames, attn_mask, attn_mask_bytes, mask_tbl, n_masks, tab);
-        } else if (f64_cmvn && !seq_split && cmvn_form != 2 && n_mels % kG == 0 && panel_bytes <= 64 * 1024 &&
-                   (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        if (f64_cmvn && !seq_split && n_mels % kG == 0 && panel_bytes <= 64 * 1024 &&
+            (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
             hipLaunchKernelGGL(kaldi_cmvn_seq_kernel<kG>, dim3((batch + 7) / 8 * 8 * (n_mels / kG)), dim3(256), panel_bytes,
                                stream, out, lengths, batch, n_mels, t_max, max_frames, attn_mask, attn_mask_bytes,
                                mask_tbl, n_masks, tab);
