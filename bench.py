@@ -107,20 +107,29 @@ def profile_traffic(workload: str, clips_per_launch: float):
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh processes (one per GPU, RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* in their environment, the same command line), relay rank 0's JSON line, return the worst
-    exit code.  The parent never touches the GPU and never replaces itself; children are stopped by PID."""
+    exit code.  The parent never touches the GPU and never replaces itself; children are stopped by PID.
+    Every rank's stdout and stderr go to files of their own in a temporary directory; the tail of every rank that exits
+    non-zero (and of the ranks stopped because of it) is printed to stderr, so that a failure on rank > 0 -- an RCCL
+    rendezvous error, a fault on one GPU -- is not lost."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
-    procs = []
+    logdir = tempfile.mkdtemp(prefix="sttfe_bench_ranks_")
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+        out_path, err_path = os.path.join(logdir, f"rank{r}.out"), os.path.join(logdir, f"rank{r}.err")
+        logs.append((out_path, err_path))
+        with open(out_path, "w") as fo, open(err_path, "w") as fe:
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=fo, stderr=fe, text=True))
     worst = 0
+    failed, stopped = [], []
     pending = set(range(n))
     while pending:
         for r in sorted(pending):
@@ -129,13 +138,39 @@ def spawn_ranks(n: int) -> int:
                 continue
             pending.discard(r)
             if rc != 0:
+                if r in stopped:
+                    continue                    # ended by the terminate() below, not a failure of its own
                 worst = worst or rc
+                failed.append((r, rc))
                 for q in pending:               # a dead rank leaves the others waiting at a barrier: stop them
-                    procs[q].terminate()
+                    if q not in stopped:
+                        stopped.append(q)
+                        procs[q].terminate()
         time.sleep(0.05)
-    out = procs[0].stdout.read() if procs[0].stdout else ""
-    sys.stdout.write(out)
+
+    def tail(path, n_lines=40):
+        try:
+            with open(path) as f:
+                return "".join(f.readlines()[-n_lines:])
+        except OSError:
+            return ""
+
+    for r, rc in failed:
+        sys.stderr.write(f"[bench.py] rank {r} of {n} exited with code {rc}; last lines of its stderr / stdout:\n"
+                         f"{tail(logs[r][1])}{tail(logs[r][0], 10)}")
+    for q in stopped:
+        sys.stderr.write(f"[bench.py] rank {q} of {n} was stopped after that failure; last lines of its stderr:\n"
+                         f"{tail(logs[q][1], 15)}")
+    if not failed:
+        sys.stderr.write(tail(logs[0][1], 200))          # rank 0's own notices, as when it ran in this process
+    sys.stdout.write(tail(logs[0][0], 10 ** 6))
     sys.stdout.flush()
+    sys.stderr.flush()
+    if failed:
+        sys.stderr.write(f"[bench.py] per-rank logs kept in {logdir}\n")
+    else:
+        import shutil
+        shutil.rmtree(logdir, ignore_errors=True)
     return worst
 
 
@@ -154,6 +189,11 @@ def run_stub(args, world: int, rank: int) -> None:
             dist.barrier()
 
     barrier()
+    fail_rank = os.environ.get("STTFE_BENCH_STUB_FAIL_RANK")          # test hook: this rank dies after the first barrier
+    if fail_rank is not None and int(fail_rank) == rank:
+        sys.stderr.write(f"stub: rank {rank} fails on purpose (STTFE_BENCH_STUB_FAIL_RANK)\n")
+        sys.stderr.flush()
+        os._exit(7)
     for _ in range(args.warmup):
         step()
     t_settle = time.perf_counter()

@@ -44,3 +44,16 @@ def test_a_failing_rank_fails_the_run():
     # WORLD_SIZE that contradicts --gpus inside the children: every rank exits non-zero, the parent reports it
     r = run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "nonsense"])
     assert r.returncode != 0
+
+
+def test_a_rank_above_zero_that_dies_leaves_its_diagnostics():
+    """rank 1 exits with code 7 right after the first barrier (rank 0 is then stuck in a collective
+    and has to be stopped): the parent returns 7, prints the tail of rank 1's stderr and says which ranks it stopped."""
+    r = run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--settle-seconds", "0.05"],
+            extra_env={"STTFE_BENCH_STUB_FAIL_RANK": "1"}, timeout=180)
+    assert r.returncode == 7, (r.returncode, r.stderr[-2000:])
+    assert "rank 1 of 2 exited with code 7" in r.stderr
+    assert "fails on purpose" in r.stderr                              # the failing rank's own message came through
+    assert "rank 0 of 2 was stopped" in r.stderr
+    assert "per-rank logs kept in" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]      # no result line from a failed run
