@@ -141,6 +141,10 @@ int sttfe_whisper_logmel_static(const float* pcm, const int64_t* offsets, const 
                                       (HF:...speech_to_text.py:113-121): cells 55+ dB below their frame's peak bin then
                                       carry the float32 STFT's noise floor. */
 
+#define STTFE_KALDI_NO_MEAN 4      /* flags: utterance CMVN without the mean step (normalize_means=False): x / std(x) */
+#define STTFE_KALDI_NO_VAR 8       /* flags: ... without the variance step (normalize_vars=False): x - mean(x)
+                                      (HF:...speech_to_text.py:141-163; both set = STTFE_KALDI_NO_CMVN) */
+
 int sttfe_kaldi_tables_bytes(int n_mels, size_t* bytes);
 int sttfe_kaldi_tables_build(int n_mels, void* host_blob, size_t bytes);
 int sttfe_kaldi_mel_bank(int n_mels, float* host_dense /* [n_mels][257] */);
@@ -173,8 +177,11 @@ int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, const int32
  * Plan = the polyphase windowed-sinc kernel of torchaudio's Resample defaults (sinc_interp_hann,
  * lowpass_filter_width 6, rolloff 0.99) for one (orig_sr, new_sr) pair, built on the HOST; the caller
  * copies the blob to the device once and passes BOTH copies (the library reads the header from the
- * host copy, the kernels read the device copy).  Rates are reduced by their gcd; reduced rates above
- * 1024 return STTFE_E_UNSUPPORTED.
+ * host copy, the kernels read the device copy).  Rates are reduced by their gcd.  Reduced rates above 1024 (a speed
+ * factor such as 0.9667: 7733 : 8000, whose table would be 248 MB; torchaudio accepts any, src/data.py:144-150) get a
+ * plan WITHOUT a table -- the 32-byte header alone, taps_row == 0 -- and run through a kernel that evaluates the
+ * non-zero taps of every output sample in float64 as the table builder does (several times slower per sample than the
+ * tabled kernels); reduced rates above 2^22 return STTFE_E_UNSUPPORTED.
  */
 int sttfe_resample_plan_bytes(int orig_sr, int new_sr, size_t* bytes);
 int sttfe_resample_plan_build(int orig_sr, int new_sr, void* host_blob, size_t bytes);

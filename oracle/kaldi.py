@@ -88,19 +88,23 @@ def kaldi_fbank(wave: np.ndarray, n_mels: int = 80) -> np.ndarray:
     return np.log(mel).astype(np.float32)                         # (:1002,1015)
 
 
-def utterance_cmvn(x: np.ndarray, input_length: int, padding_value: float = 0.0) -> np.ndarray:
+def utterance_cmvn(x: np.ndarray, input_length: int, padding_value: float = 0.0, normalize_means: bool = True,
+                   normalize_vars: bool = True) -> np.ndarray:
     """HF:...speech_to_text.py:141-163, same NumPy calls (float32 in, float32 out)."""
-    mean = x[:input_length].mean(axis=0)
-    x = np.subtract(x, mean)
-    std = x[:input_length].std(axis=0)
-    x = np.divide(x, std)
+    if normalize_means:
+        mean = x[:input_length].mean(axis=0)
+        x = np.subtract(x, mean)
+    if normalize_vars:
+        std = x[:input_length].std(axis=0)
+        x = np.divide(x, std)
     if input_length < x.shape[0]:
         x[input_length:] = padding_value
     return x.astype(np.float32)
 
 
 def speech2text_features(clips, n_mels: int = 80, max_length: int | None = None,
-                         truncation: bool = False, pad_to: int | None = None):
+                         truncation: bool = False, pad_to: int | None = None, normalize_means: bool = True,
+                         normalize_vars: bool = True):
     """List of waveforms -> (features (B, T_pad, n_mels) f32, attention_mask (B, T_pad) int32, lengths).
 
     ``truncation``/``max_length`` follow HF:...speech_to_text.py:275-283 (truncate the
@@ -118,6 +122,6 @@ def speech2text_features(clips, n_mels: int = 80, max_length: int | None = None,
     mask = np.zeros((len(feats), t_pad), dtype=np.int32)
     for i, (f, n) in enumerate(zip(feats, lengths)):
         if n > 0:
-            out[i, :n] = utterance_cmvn(f, n)
+            out[i, :n] = utterance_cmvn(f, n, normalize_means=normalize_means, normalize_vars=normalize_vars)
         mask[i, :n] = 1
     return out, mask, np.asarray(lengths, dtype=np.int32)

@@ -153,21 +153,9 @@ class WaveformAugmentSampler:
         self.speed_probability = float(get("speed_probability", 0.3))
         lo, hi = get("speed_factor_range", (0.9, 1.1))
         self.speed_factors = np.linspace(lo, hi, int(get("speed_num_steps", 3))).tolist()   # src/data.py:145-149
-        if self.speed_perturbation:
-            # torchaudio accepts any ratio (it builds a new x taps table, 248 MB for 7733:8000); the resampler here
-            # keeps per-phase tap rows for reduced rates up to 1024, so a config it cannot run fails HERE, at
-            # construction, not mid-epoch when that factor happens to be drawn
-            import ctypes
-            from . import _lib
-            for f in self.speed_factors:
-                src, dst = self.speed_rates(f)
-                n = ctypes.c_size_t()
-                if src != dst and _lib.lib().sttfe_resample_plan_bytes(src, dst, ctypes.byref(n)) != 0:
-                    raise ValueError(
-                        f"speed factor {f:.6g} resamples {src}:{dst} after reduction, beyond the 1024:1024 the GPU "
-                        f"resampler supports; choose speed_factor_range / speed_num_steps so that "
-                        f"int(factor * {self.sample_rate}) shares a large divisor with {self.sample_rate} "
-                        f"(the defaults give 9:10 and 11:10)")
+        # (any speed factor is accepted, as by torchaudio: reduced ratios beyond 1024:1024 -- int(factor * sample_rate)
+        # sharing no large divisor with sample_rate -- run through the table-free resampler, see csrc/tables.cpp.
+        # Constructing the sampler touches neither the library nor the GPU: it is host configuration + RNG state.)
         self.pitch_shift = bool(get("pitch_shift", True))
         self.pitch_probability = float(get("pitch_probability", 0.3))
         self.pitch_shift_range = tuple(get("pitch_shift_range", (-2, 2)))

@@ -862,7 +862,7 @@ __global__ __launch_bounds__(kaldi64::kThreads, kaldi64::kWgPerCu) void kaldi_fb
 // stats (as float32): [clip][0][mel] = mean, [clip][1][mel] = std, inside the clip's 2 * n_mels doubles of workspace.
 __global__ __launch_bounds__(64) void kaldi_stats_seq_kernel(
     const float* __restrict__ out, const int32_t* __restrict__ lengths, float* __restrict__ stats_f32,
-    int batch, int n_mels, int t_max, int max_frames) {
+    int batch, int n_mels, int t_max, int max_frames, int flags) {
 #pragma clang fp contract(off)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= batch * n_mels) return;
@@ -901,14 +901,20 @@ __global__ __launch_bounds__(64) void kaldi_stats_seq_kernel(
         return acc;
     };
     const float fT = (float)T;
-    const float mean = sweep([](float x) { return x; }) / fT;                              // x.mean(axis=0)
-    const float arrmean = sweep([mean](float x) { return x - mean; }) / fT;                // _var: mean of x - mean
-    const float ssq = sweep([mean, arrmean](float x) {
-        const float d = (x - mean) - arrmean;
-        return d * d;
-    });
+    // normalize_means / normalize_vars individually off (HF:...speech_to_text.py:141-163): without the mean step the
+    // std is taken of x itself (x - 0.0f == x), without the variance step nothing is divided (x / 1.0f == x)
+    float mean = 0.0f, sd = 1.0f;
+    if (!(flags & STTFE_KALDI_NO_MEAN)) mean = sweep([](float x) { return x; }) / fT;      // x.mean(axis=0)
+    if (!(flags & STTFE_KALDI_NO_VAR)) {
+        const float arrmean = sweep([mean](float x) { return x - mean; }) / fT;            // _var: mean of x - mean
+        const float ssq = sweep([mean, arrmean](float x) {
+            const float d = (x - mean) - arrmean;
+            return d * d;
+        });
+        sd = sqrtf(ssq / fT);
+    }
     st[mel] = mean;
-    st[n_mels + mel] = sqrtf(ssq / fT);
+    st[n_mels + mel] = sd;
 }
 
 // out[b][t][m] <- (x - mean_m) / std_m for t < T_b, 0 for padded rows; masks <- 0; attention mask.
@@ -948,8 +954,8 @@ __global__ __launch_bounds__(256) void kaldi_cmvn_kernel(
         const double mean = st[threadIdx.x] * inv_n;
         double var = st[n_mels + threadIdx.x] * inv_n - mean * mean;
         var = var > 0.0 ? var : 0.0;
-        s_mean[threadIdx.x] = (float)mean;
-        s_std[threadIdx.x] = (float)sqrt(var);
+        s_mean[threadIdx.x] = (flags & STTFE_KALDI_NO_MEAN) ? 0.0f : (float)mean;
+        s_std[threadIdx.x] = (flags & STTFE_KALDI_NO_VAR) ? 1.0f : (float)sqrt(var);
     }
     __syncthreads();
     const bool no_cmvn = flags & STTFE_KALDI_NO_CMVN;
@@ -1000,7 +1006,7 @@ template <int G>
 __global__ __launch_bounds__(256) void kaldi_cmvn_seq_kernel(
     float* __restrict__ out, const int32_t* __restrict__ lengths, int batch, int n_mels, int t_max, int max_frames,
     void* __restrict__ attn, int attn_bytes, const int32_t* __restrict__ mask_tbl, int n_masks,
-    const KaldiTablesHeader* __restrict__ tab) {
+    const KaldiTablesHeader* __restrict__ tab, int flags) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float panel[];      // [T][G]
     __shared__ float s_mean[G], s_std[G];
@@ -1060,13 +1066,16 @@ __global__ __launch_bounds__(256) void kaldi_cmvn_seq_kernel(
         float mean = 0.0f, sd = 1.0f;
         if (T > 0) {
             const float fT = (float)T;
-            mean = sweep([](f32x2 x) { return x; }) / fT;                                  // x.mean(axis=0)
-            const float arrmean = sweep([mean](f32x2 x) { return x - mean; }) / fT;        // _var: mean of x - mean
-            const float ssq = sweep([mean, arrmean](f32x2 x) {
-                const f32x2 d = (x - mean) - arrmean;
-                return d * d;
-            });
-            sd = sqrtf(ssq / fT);
+            // (normalize_means / normalize_vars individually off: see kaldi_stats_seq_kernel)
+            if (!(flags & STTFE_KALDI_NO_MEAN)) mean = sweep([](f32x2 x) { return x; }) / fT;          // x.mean(axis=0)
+            if (!(flags & STTFE_KALDI_NO_VAR)) {
+                const float arrmean = sweep([mean](f32x2 x) { return x - mean; }) / fT;    // _var: mean of x - mean
+                const float ssq = sweep([mean, arrmean](f32x2 x) {
+                    const f32x2 d = (x - mean) - arrmean;
+                    return d * d;
+                });
+                sd = sqrtf(ssq / fT);
+            }
         }
         s_mean[chain_tid] = mean;
         s_std[chain_tid] = sd;
@@ -1125,7 +1134,8 @@ extern "C" int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, 
                                       const int32_t* mask_tbl, int n_masks,
                                       void* workspace, size_t workspace_bytes, void* stream_) {
     if (batch < 0 || n_mels < 1 || n_mels > 128 || t_max < 0 || n_masks < 0 || n_masks > STTFE_MAX_MASKS) return STTFE_E_INVALID_ARG;
-    if (flags & ~(STTFE_KALDI_NO_CMVN | STTFE_KALDI_F64)) return STTFE_E_INVALID_ARG;
+    if (flags & ~(STTFE_KALDI_NO_CMVN | STTFE_KALDI_F64 | STTFE_KALDI_NO_MEAN | STTFE_KALDI_NO_VAR)) return STTFE_E_INVALID_ARG;
+    if ((flags & STTFE_KALDI_NO_MEAN) && (flags & STTFE_KALDI_NO_VAR)) flags |= STTFE_KALDI_NO_CMVN;     // nothing left to do
     if (attn_mask && attn_mask_bytes != 4 && attn_mask_bytes != 8) return STTFE_E_INVALID_ARG;
     if (batch == 0 || t_max == 0) return STTFE_OK;
     if (!pcm || !offsets || !lengths || !dev_tables || !out || !workspace) return STTFE_E_INVALID_ARG;
@@ -1186,11 +1196,11 @@ extern "C" int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, 
             (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
             hipLaunchKernelGGL(kaldi_cmvn_seq_kernel<kG>, dim3((batch + 7) / 8 * 8 * (n_mels / kG)), dim3(256), panel_bytes,
                                stream, out, lengths, batch, n_mels, t_max, max_frames, attn_mask, attn_mask_bytes,
-                               mask_tbl, n_masks, tab);
+                               mask_tbl, n_masks, tab, flags);
         } else {
             if (f64_cmvn)
                 hipLaunchKernelGGL(kaldi_stats_seq_kernel, dim3((batch * n_mels + 63) / 64), dim3(64), 0, stream, out,
-                                   lengths, reinterpret_cast<float*>(workspace), batch, n_mels, t_max, max_frames);
+                                   lengths, reinterpret_cast<float*>(workspace), batch, n_mels, t_max, max_frames, flags);
             int cx = (t_max * n_mels + 255) / 256;
             if (cx > 64) cx = 64;
             hipLaunchKernelGGL(kaldi_cmvn_kernel, dim3(cx, batch), dim3(256), 0, stream, out, lengths, stats, n_mels,

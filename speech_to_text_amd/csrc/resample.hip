@@ -439,6 +439,75 @@ __global__ __launch_bounds__(256) void resample_generic_kernel(
     }
 }
 
+// Reduced ratios beyond 1024 : 1024 (plans without a table, tables.cpp): the non-zero taps of an output sample --
+// those with |t| < 6, about 12 max(orig, new) / new of them -- are evaluated where they are used, as the table builder
+// evaluates them: t in float64, sin(pi t) / (pi t) * cos^2(pi t / 12) * scale rounded to float32 once.  sin and cos of
+// consecutive taps advance by fixed float64 rotations (two sincos per output instead of two per tap; the rotation error,
+// ~1e-16 per step over a dozen steps, moves the float32 rounding of a tap only when the exact value sits within 1e-15
+// of a rounding boundary).  Same accumulation order as resample_generic_kernel (ascending k, fmaf).
+template <typename TIn>
+__global__ __launch_bounds__(256) void resample_onthefly_kernel(
+    const TIn* __restrict__ pcm_in, const int64_t* __restrict__ in_off, const int32_t* __restrict__ in_len,
+    int channels, const ResamplePlanHeader* __restrict__ plan, float* __restrict__ pcm_out,
+    const int64_t* __restrict__ out_off, int32_t* __restrict__ out_len, unsigned* __restrict__ peak_keys) {
+    const int clip = blockIdx.y;
+    const int n = in_len[clip];
+    const int orig = plan->orig_rate, nw = plan->new_rate, width = plan->width;
+    const int n_out = (int)(((int64_t)nw * n + orig - 1) / orig);
+    if (blockIdx.x == 0 && threadIdx.x == 0) out_len[clip] = n_out;
+    const TIn* __restrict__ x = pcm_in + in_off[clip];
+    float* __restrict__ y = pcm_out + out_off[clip];
+    const double base = (double)(orig < nw ? orig : nw) * 0.99;
+    const double scale = base / (double)orig, inv_orig = 1.0 / (double)orig;
+    double rot_s, rot_c, rot_sw, rot_cw;
+    sincos(M_PI * scale, &rot_s, &rot_c);                      // t advances by base / orig = scale per tap
+    sincos(M_PI * scale / 12.0, &rot_sw, &rot_cw);
+    const int half = (int)ceil(6.0 / scale) + 1;               // taps either side of t = 0 that can be non-zero
+    float peak = 0.f;
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += gridDim.x * blockDim.x) {
+        const int blk = o / nw, ph = o - blk * nw;
+        const int64_t s0 = (int64_t)blk * orig - width;         // sample under tap k = 0
+        // torch: arange(0, -new, -1) / new is an int64 / int true division -> a float32 quotient
+        const double phase = (double)__fdiv_rn((float)(-ph), (float)nw);
+        const int centre = width + (int)(((int64_t)ph * orig) / nw);         // tap nearest t = 0
+        int k0 = centre - half, k1 = centre + half + 1;
+        k0 = k0 < 0 ? 0 : k0;
+        k1 = k1 > 2 * width + orig ? 2 * width + orig : k1;
+        double sn, cs, sw, cw;
+        {
+            const double t0 = (phase + (double)(k0 - width) * inv_orig) * base;
+            sincos(t0 * M_PI, &sn, &cs);
+            sincos(t0 * M_PI / 12.0, &sw, &cw);
+        }
+        float acc = 0.f;
+        for (int k = k0; k < k1; ++k) {
+            const double t = (phase + (double)(k - width) * inv_orig) * base;
+            const int64_t sidx = s0 + k;
+            if (sidx >= 0 && sidx < n && fabs(t) < 6.0) {
+                const double tp = t * M_PI;
+                const double sinc = tp == 0.0 ? 1.0 : sn / tp;
+                const float tap = (float)(sinc * (cw * cw) * scale);
+                acc = fmaf(tap, mono_at(x, n, channels, (int)sidx), acc);
+            }
+            const double sn2 = sn * rot_c + cs * rot_s, sw2 = sw * rot_cw + cw * rot_sw;
+            cs = cs * rot_c - sn * rot_s;
+            cw = cw * rot_cw - sw * rot_sw;
+            sn = sn2;
+            sw = sw2;
+        }
+        y[o] = acc;
+        peak = fmaxf(peak, fabsf(acc));
+    }
+    __shared__ float s_peak[4];
+    peak = wave_max(peak);
+    if ((threadIdx.x & 63) == 0) s_peak[threadIdx.x >> 6] = peak;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = fmaxf(fmaxf(s_peak[0], s_peak[1]), fmaxf(s_peak[2], s_peak[3]));
+        if (m > 0.f) atomicMax(&peak_keys[clip], __float_as_uint(m));
+    }
+}
+
 // Any ratio, LDS-tiled (44.1 / 22.05 / 8 kHz ... sources): the one-thread-per-output kernel above reads every tap and
 // every sample from global memory with a different tap row per lane (2.9 ms for 512 Common-Voice-length clips at
 // 44.1 kHz, twenty times the 48 kHz decimator).  Here a workgroup keeps the non-zero span of every phase's taps
@@ -906,7 +975,13 @@ static int resample_peak_impl(const TIn* pcm_in, const int64_t* in_offsets, cons
         const int64_t max_out = (hp->new_rate * max_in_length + hp->orig_rate - 1) / hp->orig_rate;
         const bool fast = hp->new_rate == 1 && hp->taps_row <= rs::kTapsPerPhase * hp->orig_rate &&
                           (hp->orig_rate == 2 || hp->orig_rate == 3 || hp->orig_rate == 4 || hp->orig_rate == 6);
-        if (fast) {
+        if (hp->taps_row == 0) {                                     // a plan without a table: reduced rates beyond 1024
+            if (max_out > 0x7fffffffLL) return STTFE_E_UNSUPPORTED;
+            int bx = (int)((max_out + 256 * 2 - 1) / (256 * 2));
+            bx = bx < 1 ? 1 : (bx > 4096 ? 4096 : bx);
+            hipLaunchKernelGGL(resample_onthefly_kernel<TIn>, dim3(bx, batch), dim3(256), 0, stream, pcm_in, in_offsets,
+                               in_lengths, channels, dp, pcm_out, out_offsets, out_lengths, keys);
+        } else if (fast) {
             static const int tpb_env = getenv("STTFE_DECIMATE_TPB") ? atoi(getenv("STTFE_DECIMATE_TPB")) : 0;   // tuning knobs
             // one item per workgroup by default: on the final kernel (8-tile items, one peak atomic per workgroup, vector
             // staging) the persistent form measured 3-4 % slower (float 0.183 / 0.176 ms, int16 0.125 / 0.122 ms) and, holding

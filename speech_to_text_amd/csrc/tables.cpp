@@ -312,7 +312,7 @@ static int resample_plan(int orig_sr, int new_sr, std::vector<unsigned char>& bl
     int a = orig_sr, b = new_sr;
     while (b) { const int t = a % b; a = b; b = t; }
     const int orig = orig_sr / a, nw = new_sr / a;
-    if (orig > 1024 || nw > 1024) return STTFE_E_UNSUPPORTED;
+    if (orig > (1 << 22) || nw > (1 << 22)) return STTFE_E_UNSUPPORTED;
     const double lowpass_width = 6.0, rolloff = 0.99;
     const double base = (double)std::min(orig, nw) * rolloff;
     const int width = (int)std::ceil(lowpass_width * orig / base);
@@ -326,6 +326,16 @@ static int resample_plan(int orig_sr, int new_sr, std::vector<unsigned char>& bl
     h.width = width;
     h.n_taps = n_taps;
     h.taps_row = row;
+    if (orig > 1024 || nw > 1024) {
+        // Reduced rates beyond 1024 (torchaudio accepts any: speed factors such as 0.97 give 97:100 -- fine -- but
+        // int(0.966625 * 16000) = 15466 gives 7733:8000, a 8000 x 7747 table of 248 MB): no table.  The plan is its
+        // header alone (taps_row = 0 marks it) and resample_onthefly_kernel evaluates the dozen non-zero taps of an
+        // output sample as the table builder below does.
+        h.taps_row = 0;
+        blob.resize(sizeof(h));
+        std::memcpy(blob.data(), &h, sizeof(h));
+        return STTFE_OK;
+    }
     std::vector<int32_t> lo(nw), hi(nw);
     std::vector<float> taps((size_t)nw * row, 0.0f);
     const double scale = base / orig;

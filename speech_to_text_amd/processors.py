@@ -334,8 +334,6 @@ class HipSpeech2TextFeatureExtractor:
                  stft_precision: str = "float64", **kwargs):
         if sampling_rate != 16000:
             raise ValueError("the HIP kernels implement sampling_rate=16000")
-        if do_ceptral_normalize and not (normalize_means and normalize_vars):
-            raise ValueError("the HIP CMVN pass normalises means and variances together (the reference's configuration)")
         if not 1 <= num_mel_bins <= 128:
             raise ValueError("num_mel_bins must be in [1, 128]")
         if stft_precision not in ("float64", "float32"):
@@ -346,8 +344,8 @@ class HipSpeech2TextFeatureExtractor:
         self.sampling_rate = sampling_rate
         self.padding_value = padding_value
         self.do_ceptral_normalize = bool(do_ceptral_normalize)     # False: raw ln(mel), HF:...speech_to_text.py:256-262
-        self.normalize_means = True
-        self.normalize_vars = True
+        self.normalize_means = bool(normalize_means)     # individually, as HF's utterance_cmvn (:141-163)
+        self.normalize_vars = bool(normalize_vars)
         self.stft_precision = stft_precision
         self.return_attention_mask = True
         self.n_fft = 512
@@ -402,6 +400,7 @@ class HipSpeech2TextFeatureExtractor:
         if apply_cmvn is None:
             apply_cmvn = self.do_ceptral_normalize
         flags = (0 if apply_cmvn else 1) | (2 if (stft_precision or self.stft_precision) == "float64" else 0)
+        flags |= (0 if self.normalize_means else 4) | (0 if self.normalize_vars else 8)     # STTFE_KALDI_NO_MEAN / _NO_VAR
         device = pcm.device
         B = int(offsets.shape[0])
         L = _lib.lib()

@@ -107,6 +107,20 @@ def gen_s2t():
     np.savez_compressed(os.path.join(HERE, "s2t_80.npz"), **store)
 
 
+def gen_s2t_cmvn_flags():
+    """normalize_means / normalize_vars individually off (HF:...speech_to_text.py:141-163), round 3."""
+    from transformers import Speech2TextFeatureExtractor
+    rng = np.random.default_rng(2002)
+    cases = {"c0_0p7s": synth_clip(rng, 11200, zero_block=False), "c1_2s_zero_block": synth_clip(rng, 32000, zero_block=True)}
+    store = {}
+    for name, clip in cases.items():
+        store[f"{name}__pcm"] = clip
+        for tag, means, varis in (("mean_only", True, False), ("var_only", False, True)):
+            fe = Speech2TextFeatureExtractor(normalize_means=means, normalize_vars=varis)
+            store[f"{name}__{tag}"] = fe(clip, sampling_rate=16000, return_tensors="pt").input_features[0].numpy()
+    np.savez_compressed(os.path.join(HERE, "s2t_80_cmvn_flags.npz"), **store)
+
+
 def gen_selfgen():
     import torch
     from oracle import resample as R
@@ -131,6 +145,7 @@ def gen_selfgen():
 if __name__ == "__main__":
     gen_whisper()
     gen_s2t()
+    gen_s2t_cmvn_flags()
     gen_selfgen()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

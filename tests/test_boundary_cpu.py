@@ -47,7 +47,9 @@ def test_argument_validation_needs_no_gpu():
     assert L.sttfe_kaldi_fbank_cmvn(None, None, None, 1, 80, 10, 0, 0, None, None, None, 4, None, 0, None, 0, None) == -1
     assert L.sttfe_kaldi_fbank_cmvn(None, None, None, 0, 80, 10, 0, 0, None, None, None, 4, None, 0, None, 0, None) == 0
     assert L.sttfe_resample_plan_bytes(48000, 0, ctypes.byref(n)) == -1
-    assert L.sttfe_resample_plan_bytes(48000, 16001, ctypes.byref(n)) == -5      # reduced rates > 1024
+    assert L.sttfe_resample_plan_bytes(48000, 16001, ctypes.byref(n)) == 0 and n.value == 32     # reduced rates > 1024:
+    # a plan without a table (header only), run by the table-free kernel; beyond 2^22 : 2^22 unsupported
+    assert L.sttfe_resample_plan_bytes(2 ** 23 + 1, 2 ** 23, ctypes.byref(n)) == -5
     assert L.sttfe_resample_peak(None, None, None, 1, 1, 10, None, None, None, None, None, None, 0, None) == -1
     assert L.sttfe_normalize_trim(None, None, None, 1, 10, 1, 1, ctypes.c_float(0.01), None, 0, None) == -1
     assert L.sttfe_normalize_trim(None, None, None, 1, 10, 0, 0, ctypes.c_float(0.01), None, 0, None) == 0

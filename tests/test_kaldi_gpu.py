@@ -232,3 +232,42 @@ def test_fused_and_split_cmvn_are_bit_identical_and_long_clips(fe, monkeypatch):
     exp, _, tl = speech2text_features(long_clip)
     assert got.shape == exp.shape and tl[0] == 2698
     assert float(np.abs(got - exp).max()) <= TOL
+
+
+@pytest.mark.parametrize("mode", ["float64", "float32"])
+@pytest.mark.parametrize("tag,means,varis", [("mean_only", True, False), ("var_only", False, True)])
+def test_cmvn_means_or_vars_alone_match_hf_goldens(mode, tag, means, varis, monkeypatch):
+    """normalize_means / normalize_vars individually off (HF:...speech_to_text.py:141-163) as two flags
+    of the CMVN kernels, against goldens from the real HF extractor.  float64 mode: flat 1e-4 (fused and two-kernel
+    forms); float32 mode: the raw log-mel differs by the float32 STFT's noise floor (module docstring), so the mean-only
+    output is held to the raw bound and the variance-only output to the raw bound divided by the bin's std."""
+    from speech_to_text_amd.processors import HipSpeech2TextFeatureExtractor
+    from oracle.kaldi import kaldi_fbank
+    z = load_golden("s2t_80_cmvn_flags.npz")
+    for split in ([False, True] if mode == "float64" else [False]):
+        if split:
+            monkeypatch.setenv("STTFE_KALDI_SPLIT_CMVN", "1")
+        fx = HipSpeech2TextFeatureExtractor(normalize_means=means, normalize_vars=varis, stft_precision=mode, device="cuda:0")
+        for name in sorted({k.split("__")[0] for k in z.files if k.endswith("__pcm")}):
+            clip, exp = z[f"{name}__pcm"], z[f"{name}__{tag}"]
+            got = fx(clip, sampling_rate=16000, return_tensors="pt").input_features[0].cpu().numpy()
+            assert got.shape == exp.shape
+            d = np.abs(got - exp)
+            if mode == "float64":
+                assert float(d.max()) <= TOL, (name, tag, split, float(d.max()))
+            else:
+                raw_ref = kaldi_fbank(clip).astype(np.float64)
+                bound = raw_bound(clip, raw_ref)
+                std = raw_ref.std(axis=0, keepdims=True)
+                b_rms = np.sqrt((bound ** 2).mean(axis=0, keepdims=True))
+                if varis:       # y = x / std: d y <= d x / std + |x| / std * (d std / std)
+                    zz = np.abs(raw_ref) / std
+                    bound = bound / std + zz * b_rms / std + 2e-5 * (1.0 + zz)
+                else:           # y = x - mean
+                    bound = bound + bound.mean(axis=0, keepdims=True) + 2e-5
+                assert (d <= bound).all(), (name, tag, float((d / bound).max()))
+    # both off is "no CMVN"
+    fx = HipSpeech2TextFeatureExtractor(normalize_means=False, normalize_vars=False, device="cuda:0")
+    clip = z["c0_0p7s__pcm"]
+    got = fx(clip, sampling_rate=16000, return_tensors="pt").input_features[0].cpu().numpy()
+    assert float(np.abs(got - kaldi_fbank(clip)).max()) <= TOL

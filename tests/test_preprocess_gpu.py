@@ -43,6 +43,31 @@ def test_resample_matches_oracle(sr):
     assert p.lengths.cpu().tolist() == p.host_lengths
 
 
+@pytest.mark.parametrize("src,dst,channels", [(2062, 2048, 1), (15466, 16000, 1), (16000, 15466, 2), (2048, 2062, 1)])
+def test_reduced_rates_beyond_1024_run_without_a_table(src, dst, channels):
+    """ratios whose reduced rates exceed 1024 (1031:1024, 7733:8000 -- the speed factor 0.9667 --
+    and their inverses) have no tap table (it would be up to 248 MB); resample_onthefly_kernel evaluates the taps where
+    they are used.  Held to the oracle, which does build the table, at the tolerance of the tabled kernels."""
+    from speech_to_text_amd.preprocess import GpuAudioPreprocessor, ResamplePlan
+    plan = ResamplePlan(src, dst)
+    assert plan.taps_row == 0 and max(plan.orig, plan.new) > 1024            # header-only plan
+    pre = GpuAudioPreprocessor(sample_rate=dst, normalize=False, trim_silence=False, min_duration=0.0, max_duration=1e9,
+                               device=DEV)
+    lens = [3 * plan.orig + 17, plan.orig - 1, 1, 40, 2 * plan.orig]
+    rng = np.random.default_rng(9)
+    clips = [make(16000, n, 300 + i) for i, n in enumerate(lens)]
+    if channels == 2:
+        clips = [np.stack([c, (0.5 * rng.standard_normal(len(c))).astype(np.float32)]) for c in clips]
+    p = pre.preprocess_batch(clips, src)
+    peaks = pre.last_peaks.cpu().numpy()
+    for i, c in enumerate(clips):
+        exp = R.resample(R.to_mono(c), src, dst)
+        assert p.host_lengths[i] == exp.shape[0]
+        got = p.clip(i)[0].cpu().numpy()
+        assert np.abs(got - exp).max() <= 2e-6, (src, dst, lens[i], float(np.abs(got - exp).max()))
+        assert peaks[i] == np.abs(got).max()
+
+
 def test_same_rate_peak_normalise_bit_exact():
     from speech_to_text_amd.preprocess import GpuAudioPreprocessor
     pre = GpuAudioPreprocessor(normalize=True, trim_silence=False, min_duration=0.0, max_duration=1e9, device=DEV)

@@ -86,16 +86,19 @@ def test_oracle_fade_and_gain_properties():
     assert np.all(np.diff(y[:1600]) > 0) and np.all(np.diff(y[-1600:]) < 0)
 
 
-def test_unsupported_speed_ratio_fails_at_construction():
-    """speed_num_steps=4 gives the factor 0.9667 -> int(15466.67) = 15466 : 16000 = 7733 : 8000 after reduction, which the
-    GPU resampler cannot run (reduced rates above 1024).  The sampler refuses the config when it is built, instead of
-    raising mid-epoch when that factor is drawn; the default (3 steps: 9:10, 1:1, 11:10) and 5 steps are fine."""
-    import pytest
+def test_any_speed_ratio_is_accepted_and_the_sampler_needs_no_library(monkeypatch):
+    """torchaudio accepts any speed factor (src/data.py:144-150); so does the sampler.  speed_num_steps=4 gives the factor
+    0.9667 -> int(15466.67) = 15466 : 16000 = 7733 : 8000 after reduction, which runs through the table-free resampler
+    (tests/test_preprocess_gpu.py::test_reduced_rates_beyond_1024...).  Building the sampler is host configuration +
+    RNG state only: it must not load libsttfe.so (CPU-only dataloader workers, config validation)."""
+    from speech_to_text_amd import _lib
     from speech_to_text_amd.augment import WaveformAugmentSampler
-    WaveformAugmentSampler()                                   # defaults
-    WaveformAugmentSampler(speed_num_steps=5)                  # 0.9, 0.95, 1.0, 1.05, 1.1 -> 9:10, 19:20, 21:20, 11:10
-    with pytest.raises(ValueError, match="beyond the 1024:1024"):
-        WaveformAugmentSampler(speed_num_steps=4)
-    with pytest.raises(ValueError, match="beyond the 1024:1024"):
-        WaveformAugmentSampler(speed_num_steps=7)
-    WaveformAugmentSampler(speed_num_steps=4, speed_perturbation=False)     # not used -> not checked
+
+    def boom(*a, **k):
+        raise AssertionError("the sampler constructor touched the library")
+    monkeypatch.setattr(_lib, "lib", boom)
+    WaveformAugmentSampler()                                   # defaults: 9:10, 1:1, 11:10
+    WaveformAugmentSampler(speed_num_steps=5)                  # 9:10, 19:20, 21:20, 11:10
+    s4 = WaveformAugmentSampler(speed_num_steps=4)
+    assert s4.speed_rates(s4.speed_factors[1]) == (7733, 8000)
+    WaveformAugmentSampler(speed_num_steps=7)
