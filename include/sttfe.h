@@ -105,8 +105,10 @@ int sttfe_whisper_logmel_scaled(const float* pcm, const int64_t* offsets, const 
  *   variable_length = 1 (padding=False, :222-239): no padding -- reflect at the clip's own end, 1 + lengths[b] / 160
  *       frames, per-clip max over them, cropped to 3000; out is [batch][n_mels][n_frames] with n_frames >= the longest
  *       clip's (cropped) frame count and a multiple of 4; frames past a clip's own are padding_value.  Clips need more
- *       than 200 samples (torch.stft's reflect padding raises below that; here such clips give unspecified values) and
- *       at most 483 680 samples count (3024 frames; the reference has no limit). */
+ *       than 200 samples (torch.stft's reflect padding raises below that; here such clips give unspecified values).
+ *       Clips with more than n_frames frames are transformed to their own end: the frames behind the output count for
+ *       the maximum and are not stored -- the reference crops after the maximum (src/processors.py:226-239).  (Calls
+ *       with more than 16 384 clips look at most 3024 frames far.) */
 int sttfe_whisper_logmel_torch(const float* pcm, const int64_t* offsets, const int32_t* lengths,
                                int batch, int n_mels, int n_frames, const void* dev_tables,
                                float* out, const int32_t* mask_tbl, int n_masks, int variable_length,

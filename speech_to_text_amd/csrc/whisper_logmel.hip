@@ -58,7 +58,8 @@ constexpr int kFramesPerWave = 12;            // two passes of 3 pairs
 constexpr int kHop = 160;
 constexpr int kNfft = 400;
 constexpr int kMaxSamples = 480000;           // 30 s at 16 kHz (HF:...whisper.py:91)
-constexpr int kVarMaxSamples = 160 * 3023;    // variable-length mode: clips of up to 3024 frames (63 tiles)
+constexpr int kVarMaxSamples = 1 << 28;       // variable-length mode: the clip's own length counts (no 30 s cut: the
+                                              // reference crops AFTER the maximum, src/processors.py:226-239)
 // Which frames count and how clips end (reference src/processors.py:180-239 differs from HF in both):
 constexpr int kModeHF = 0;          // pad / truncate to 30 s, last frame dropped before the per-clip max (HF)
 constexpr int kModeTorchPadded = 1; // pad / truncate to 30 s, per-clip max over all 3001 frames, then crop (:206-219)
@@ -275,7 +276,11 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     // Thread 0 requests the ticket two items ahead and publishes it through LDS at the end of an item, so that the
     // atomic, the length / offset of the next item and its first PCM tile are all in flight under useful work.
     // Every workgroup leaves its loop after at most n_items tickets; all threads of a workgroup take the same path.
-    const int n_tiles = (n_frames + kTileFrames - 1) / kTileFrames;
+    // tiles a clip can have: those of the output -- except in variable-length mode, where a clip longer than the output
+    // (more than 3000 frames) is transformed to its own end for the per-clip maximum and only stored up to n_frames
+    // (batches of more than 16384 clips, whose lengths are not reduced below, stop at 63 tiles as before)
+    const int n_tiles = mode == kModeTorchVarlen ? (kVarMaxSamples / kHop + kTileFrames) / kTileFrames
+                                                 : (n_frames + kTileFrames - 1) / kTileFrames;
     const int len_cap = mode == kModeTorchVarlen ? kVarMaxSamples : kMaxSamples;
     auto clamp_len = [len_cap](int n) { return n < 0 ? 0 : (n > len_cap ? len_cap : n); };
     // first tile that lies entirely in the padding (those are constant: kernel 2 fills them): past the last frame that
@@ -876,7 +881,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         }   // generic unit loop
         // per-tile minimum (kernel 2 re-reads only the tiles that hold something below max - 8)
         tile_min = wave_min(tile_min);
-        if (lane == 0 && tile_min < 1.0e38f)
+        if (lane == 0 && tile_min < 1.0e38f && tile < kMaxTiles)       // (tiles behind the output have no min key: not stored)
             atomicMax(&keys[(size_t)clip * kKeysPerClip + 1 + tile], ~float_to_key(__log2f(tile_min) * 0.30102999566398120f));
         STAMP(7);
         __syncthreads();      // panel reads done before the next tile's slab writes

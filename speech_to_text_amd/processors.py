@@ -263,10 +263,9 @@ class TorchWhisperFeatureExtractor(HipWhisperFeatureExtractor):
 
     One deliberate difference: the mel bank is HF's (slaney scale), the parity target of this build, not the
     HTK-scale bank of src/processors.py:75-83.  ``padding=False`` needs clips of more than 200 samples (torch.stft's
-    reflect padding raises below that, and so does this class) and of at most 483 680 samples (30.23 s).
+    reflect padding raises below that, and so does this class); clips longer than 30 s are transformed to their own
+    end for the per-clip maximum and cropped to 3000 frames afterwards, as in the reference.
     """
-
-    MAX_VARLEN_SAMPLES = 160 * 3023
 
     def extract_torch(self, pcm: torch.Tensor, offsets: torch.Tensor, lengths: torch.Tensor, n_frames: int,
                       variable_length: bool) -> torch.Tensor:
@@ -306,11 +305,11 @@ class TorchWhisperFeatureExtractor(HipWhisperFeatureExtractor):
             if min(lens) <= self.n_fft // 2:
                 raise ValueError(f"padding=False needs clips longer than {self.n_fft // 2} samples (reflect padding of "
                                  f"the STFT); got {min(lens)}")
-            if max(lens) > self.MAX_VARLEN_SAMPLES:
-                raise ValueError(f"padding=False handles clips of up to {self.MAX_VARLEN_SAMPLES} samples; got "
-                                 f"{max(lens)}: truncate to {self.chunk_length} s first")
+            # clips longer than 30 s: the reference transforms the whole clip, takes the maximum over ALL its frames and
+            # crops to 3000 afterwards (src/processors.py:226-239); so does the kernel (tiles behind the output only
+            # feed the per-clip maximum)
             frames = min(max(1 + n // self.hop_length for n in lens), self.expected_frames)
-            pcm, offsets, lengths = pack_clips(clips, device, self.MAX_VARLEN_SAMPLES)
+            pcm, offsets, lengths = pack_clips(clips, device, max(lens))
             feats = self.extract_torch(pcm, offsets, lengths, (frames + 3) // 4 * 4, True)[:, :, :frames]
         if return_tensors != "pt":
             feats = feats.detach().cpu().numpy()
