@@ -75,8 +75,12 @@ int sttfe_whisper_workspace_bytes(int batch, size_t* bytes);
  *                       multiple of 4 with 160 * n_frames >= lengths[b] + 200 + 4 * 160 for every clip gives columns
  *                       bit-identical to the first n_frames of the 3000-frame result, the last 4 of them padding for
  *                       every clip (out[b][0][n_frames - 1] is clip b's padding constant); the 30 s padding behind them
- *                       is then neither computed nor written.  The caller guarantees the bound (it is not checked:
- *                       a longer clip is the HF extractor run with n_samples = 160 * n_frames).
+ *                       is then neither computed nor written.  The caller guarantees the bound; it is not checked
+ *                       here (the lengths are device data).  With a longer clip the columns written are still those of
+ *                       the 3000-frame result -- the kernel keeps reading the clip's samples and reflects at 480000,
+ *                       not at 160 * n_frames -- but the last columns are then data, not padding, and
+ *                       out[b][0][n_frames - 1] is not the padding constant (host callers that know the lengths check:
+ *                       HipWhisperFeatureExtractor.extract(host_lengths=), FeatureCacheWriter.add_batch).
  * mask_tbl            : device int32 [batch][n_masks][3] = {axis, start, end} or NULL; elements
  *                       with start <= index < end along the axis are set to 0.0 AFTER the
  *                       log/clamp/scale (SpecAugment, src/data.py:185-194); rows with end<=start
@@ -121,7 +125,9 @@ int sttfe_whisper_logmel_torch(const float* pcm, const int64_t* offsets, const i
  * 4 * (64 * STTFE_WHISPER_STATIC_MAX_BATCH + 16) bytes (1 MiB + 64 B) on every GPU the library runs on, held until the
  * process ends.  batch > STTFE_WHISPER_STATIC_MAX_BATCH returns STTFE_E_UNSUPPORTED (sttfe_last_error_detail() says
  * why).  The call allocates and frees nothing (the array's device address is looked up once per device, on the first
- * call made with that device current).  All calls on one GPU share that GPU's array: the entry point clears the part
+ * call made with that device current: hipGetSymbolAddress, which may load the code object and is not legal under
+ * stream capture -- make ONE ordinary warm-up call per device (any batch >= 1) before the first captured or
+ * allocation-forbidden one; every later call on that device only launches).  All calls on one GPU share that GPU's array: the entry point clears the part
  * it uses on `stream` before its kernels run, and two calls that overlap on one GPU (different streams, or different
  * host threads on different streams) race -- serialise them, or use sttfe_whisper_logmel with separate workspaces. */
 #define STTFE_WHISPER_STATIC_MAX_BATCH 4096

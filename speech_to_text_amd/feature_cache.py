@@ -84,7 +84,14 @@ class FeatureCacheWriter:
         if self.model_type == "whisper":
             # a compact batch (extract(..., n_frames=whisper_compact_frames(lengths))) has fewer columns than 3000:
             # its last column is still every clip's padding constant
-            keep = [min(whisper_computed_frames(n, self.n_frames), int(features.shape[2])) for n in n_samples]
+            T = int(features.shape[2])
+            if T < self.n_frames and whisper_compact_frames(n_samples, self.n_frames) > T:
+                # the compact contract is the CALLER's promise (the kernel cannot check lengths against n_frames without
+                # a synchronisation): here the lengths are on the host, so a batch that breaks it is refused instead of
+                # being stored with a wrong padding constant
+                raise ValueError(f"compact batch of {T} frames is too short for its longest clip: "
+                                 f"whisper_compact_frames(n_samples) = {whisper_compact_frames(n_samples, self.n_frames)}")
+            keep = [min(whisper_computed_frames(n, self.n_frames), T) for n in n_samples]
         else:
             keep = [int(f) for f in (frames if frames is not None else [features.shape[2]] * B)]
         t_max = max(keep) if keep else 0

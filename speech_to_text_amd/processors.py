@@ -175,7 +175,8 @@ class HipWhisperFeatureExtractor:
 
     def extract(self, pcm: torch.Tensor, offsets: torch.Tensor, lengths: torch.Tensor,
                 mask_table: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                clip_scale: Optional[torch.Tensor] = None, n_frames: Optional[int] = None) -> torch.Tensor:
+                clip_scale: Optional[torch.Tensor] = None, n_frames: Optional[int] = None,
+                host_lengths: Optional[Sequence[int]] = None) -> torch.Tensor:
         """Device-resident entry: packed PCM + per-clip offsets/lengths -> (B, M, 3000) float32.
 
         ``n_frames`` (a multiple of 4, default 3000): the COMPACT output contract for callers that keep "frames + padding
@@ -183,7 +184,11 @@ class HipWhisperFeatureExtractor:
         columns are produced.  They are bit-identical to the same columns of the 3000-frame result as long as every
         clip's audio ends before them -- ``n_frames >= whisper_compact_frames(lengths)``, which the caller guarantees
         (it knows the lengths on the host; the last 4 columns are then padding for every clip, so ``out[b, 0, -1]`` is
-        clip b's padding constant).  A shorter ``n_frames`` is the HF extractor run with that ``n_samples``.
+        clip b's padding constant).  With a shorter ``n_frames`` the columns are still those of the 30 s result (the
+        kernel keeps reading the clip's real samples and reflects at 30 s, not at ``160 * n_frames``) but the last
+        columns are no longer padding and ``out[b, 0, -1]`` is not the padding constant: pass ``host_lengths`` (the
+        clip lengths, known on the host) to have the bound checked here -- it cannot be checked on the device without
+        a synchronisation.
 
         ``clip_scale`` (device float32 (B,)): the features of ``clip_scale[b] * clip_b`` without touching the
         samples (``sttfe_whisper_logmel_scaled``) -- the peak normalisation of ``GpuAudioPreprocessor.run(...,
@@ -196,6 +201,12 @@ class HipWhisperFeatureExtractor:
         T = int(n_frames)
         if T < 4 or T > self.nb_max_frames or T % 4:
             raise ValueError(f"n_frames must be a multiple of 4 in [4, {self.nb_max_frames}], got {n_frames}")
+        if host_lengths is not None and T < self.nb_max_frames:
+            from .feature_cache import whisper_compact_frames
+            need = whisper_compact_frames(host_lengths, self.nb_max_frames)
+            if need > T:
+                raise ValueError(f"compact output of {T} frames is too short for the longest clip (needs {need}): "
+                                 "its last columns would not be padding")
         if out is None:
             out = torch.empty((B, self.feature_size, T), dtype=torch.float32, device=device)
         elif tuple(out.shape) != (B, self.feature_size, T) or not out.is_contiguous() or out.dtype != torch.float32:

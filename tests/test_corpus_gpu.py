@@ -125,6 +125,11 @@ def test_compact_frames_rule_and_argument_checks(corpus):
         fe.extract(pcm2d.reshape(-1), offsets[:4], lengths[:4], n_frames=1002)
     with pytest.raises(ValueError):
         fe.extract(pcm2d.reshape(-1), offsets[:4], lengths[:4], n_frames=3004)
+    # the compact contract is checked where the lengths are known on the host
+    hl = [int(v) for v in lens[:4]]
+    with pytest.raises(ValueError, match="too short for the longest clip"):
+        fe.extract(pcm2d.reshape(-1), offsets[:4], lengths[:4], n_frames=whisper_compact_frames(hl) - 4, host_lengths=hl)
+    fe.extract(pcm2d.reshape(-1), offsets[:4], lengths[:4], n_frames=whisper_compact_frames(hl), host_lengths=hl)
     # the rule is tight at its boundary: clips cut to 160 k - 200 (+1) samples
     for n in (160 * 52 - 200, 160 * 52 - 199, 160 * 50 - 199, 37, 0):
         ln = torch.tensor([n, n // 2], dtype=torch.int32, device=DEV)

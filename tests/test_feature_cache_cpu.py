@@ -109,3 +109,19 @@ def test_compact_batches_round_trip_and_by_length_chunks(tmp_path):
     for i in range(len(lens)):
         assert a[i]["id"] == b[i]["id"] == i
         assert torch.equal(a[i]["input_features"], full[i]) and torch.equal(b[i]["input_features"], full[i])
+
+
+def test_a_compact_batch_that_breaks_the_contract_is_refused(tmp_path):
+    """a compact (n_frames < 3000) batch whose longest clip needs more columns would be stored with a wrong
+    padding constant; add_batch knows the lengths and refuses it."""
+    import pytest
+    import torch
+    from speech_to_text_amd.feature_cache import FeatureCacheWriter, whisper_compact_frames
+    w = FeatureCacheWriter(str(tmp_path / "c"), "whisper", 80)
+    n = [16000, 52000]
+    T = whisper_compact_frames(n)
+    feats = torch.full((2, 80, T), -0.25)
+    w.add_batch([0, 1], feats, n)                                  # fits
+    with pytest.raises(ValueError, match="too short for its longest clip"):
+        w.add_batch([2, 3], feats[:, :, :T - 4], n)
+    w.close()
