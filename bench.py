@@ -92,6 +92,13 @@ def cpu_baseline(workload: str, n_mels: int, clips_np):
             "sample": f"{len(clips_np)} clips ({audio_s / reps:.0f} audio-s) x {reps} passes of {what}"}
 
 
+def computed_frames(n16):
+    """Frames of each clip that the Whisper STFT kernel computes and writes: whole 48-frame tiles up to the first tile
+    that lies entirely in the zero padding (csrc/whisper_logmel.hip, first_pad_tile_of), at most 3000."""
+    n16 = np.asarray(n16, dtype=np.int64)
+    return np.minimum(3000, (n16 + 200 + 7679) // 7680 * 48)
+
+
 def profile_traffic(workload: str, clips_per_launch: float):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (None if not covered)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
@@ -102,6 +109,58 @@ def profile_traffic(workload: str, clips_per_launch: float):
     except Exception:
         pass
     return None
+
+
+def e2e_lines(wl: str, device, n_mels: int, sr: int, seed: int, batches: int = 10):
+    """SURVEY.md 8(d) "one end-to-end line including pinned-H2D": host clips -> PinnedIngestRing (host memcpy into a
+    pinned slot by a few threads, asynchronous H2D on the ring's stream, the copy of batch k + 1 under the kernels of
+    batch k) -> [48 -> 16 kHz resample + peak normalise] -> Whisper features, for float32 and for int16 decoded PCM.
+    Measured AFTER the timed region on a bounded number of batches; reported beside `value`, never mixed into it."""
+    import torch
+    from speech_to_text_amd.preprocess import GpuAudioPreprocessor, PinnedIngestRing
+    from speech_to_text_amd.processors import HipWhisperFeatureExtractor
+    from speech_to_text_amd.synth import common_voice_lengths, synth_batch
+    B = 256
+    rng = np.random.default_rng(seed)
+    if wl == "whisper80":
+        base = synth_batch(seed, [N_SAMPLES] * 4, sample_rate=sr)
+        clips32 = [base[i % 4] for i in range(B)]
+    else:
+        lens = (common_voice_lengths(rng, 16) * 3).tolist()
+        base = synth_batch(seed, lens, sample_rate=sr)
+        clips32 = [base[i % 16] for i in range(B)]
+    clips16 = [np.clip(np.round(c * 32767.0), -32768, 32767).astype(np.int16) for c in clips32[:16]]
+    clips16 = [clips16[i % len(clips16)] for i in range(B)] if wl != "whisper80" else [clips16[i % 4] for i in range(B)]
+    fe = HipWhisperFeatureExtractor(n_mels, device=device)
+    pre = GpuAudioPreprocessor(normalize=(wl != "whisper80"), trim_silence=False, min_duration=0.0, max_duration=1e9,
+                               device=device)
+    out = torch.empty((B, n_mels, 3000), dtype=torch.float32, device=device)
+    audio_s = sum(len(c) for c in clips32) / sr
+    lines = {}
+    for name, clips in (("float32", clips32), ("int16", clips16)):
+        ring = PinnedIngestRing(device, slots=3, fill_threads=4)
+
+        def run(n):
+            tickets = [ring.submit(clips), ring.submit(clips)]
+            for k in range(n):
+                pcm, off, ln, lens_h, ch = ring.take(tickets.pop(0))
+                p = pre.run(pcm, off, ln, lens_h, ch, sr, sync_lengths=False)
+                fe.extract(p.pcm, p.offsets, p.lengths, out=out)
+                if k + 2 < n:
+                    tickets.append(ring.submit(clips))
+            torch.cuda.synchronize()
+
+        run(3)
+        t0 = time.perf_counter()
+        run(batches)
+        dt = time.perf_counter() - t0
+        wire = sum(c.nbytes for c in clips) * batches
+        lines[name] = {"value": audio_s * batches / dt, "unit": "audio-s/s", "pcie_gbs": wire / dt / 1e9,
+                       "ms_per_batch": dt / batches * 1e3}
+        del ring
+    return {"path": "host clips -> PinnedIngestRing (4 fill threads, 3 pinned slots, async H2D) -> "
+                    + ("" if wl == "whisper80" else "48 -> 16 kHz resample + peak normalise -> ") + f"Whisper {n_mels}-mel",
+            "clips_per_batch": B, "batches": batches, **lines}
 
 
 def spawn_ranks(n: int) -> int:
@@ -247,6 +306,7 @@ def main():
                     choices=["whisper80", "s2t", "s2t_f32", "resample_whisper", "resample_whisper_s16", "whisper128_aug", "corpus", "corpus_compact"])
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (0 = the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (host clips -> features) lines")
     ap.add_argument("--fused-normalize", action="store_true",
                     help="resample_whisper workloads: peak normalisation folded into the Whisper kernel "
                          "(sttfe_whisper_logmel_scaled) instead of a pass of its own")
@@ -376,7 +436,11 @@ def main():
         else:
             chunk_T = {c0: 3000 for c0 in range(0, n_local, B)}
         out_cols = sum(T * (min(c0 + B, n_local) - c0) for c0, T in chunk_T.items())
-        bytes_per_launch = float(4 * np.minimum(lens, N_SAMPLES).sum() + 4 * n_mels * out_cols)   # per pass over the shard
+        step_bytes = float(4 * np.minimum(lens, N_SAMPLES).sum() + 4 * n_mels * out_cols)   # per pass over the shard
+        # roofline.frac credits the STFT kernel with what IT moves: its input and the columns of the tiles it computes
+        # (the padding behind them is written by the clamp / fill kernel and counts in whole_step_frac only)
+        own_cols = sum(int(np.minimum(computed_frames(lens[c0:min(c0 + B, n_local)]), T).sum()) for c0, T in chunk_T.items())
+        bytes_per_launch = float(4 * np.minimum(lens, N_SAMPLES).sum() + 4 * n_mels * own_cols)
         chunk = [0]
 
         def step(slot=0):
@@ -392,8 +456,12 @@ def main():
         fe = HipWhisperFeatureExtractor(n_mels, device=device)
         outs = [torch.empty((B, n_mels, 3000), dtype=torch.float32, device=device) for _ in range(n_slots)]
         kernel, kname = "whisper_stft_mel", "whisper_stft_mel_kernel"
-        valid16 = np.minimum(lens // (3 if sr == 48000 else 1), N_SAMPLES)
-        bytes_per_launch = float(4 * valid16.sum() + 4 * n_mels * 3000 * B)
+        valid16 = np.minimum(-(-lens // 3) if sr == 48000 else lens, N_SAMPLES)
+        # roofline.frac: the bytes the STFT kernel itself moves -- its 16 kHz input and the columns of the tiles it
+        # computes; the 30 s padding behind them is the clamp / fill kernel's and counts in whole_step_frac only
+        # (crediting the kernel with the whole tensor flattered it on ragged batches)
+        bytes_per_launch = float(4 * valid16.sum() + 4 * n_mels * computed_frames(valid16).sum())
+        step_bytes = float(4 * valid16.sum() + 4 * n_mels * 3000 * B)
         if wl == "resample_whisper":
             # the whole step's algorithmic bytes count the input at the SOURCE rate: 4 n_in (2 n_in for
             # int16 PCM) + the feature tensor; the 16 kHz intermediate is not algorithmic traffic
@@ -580,6 +648,8 @@ def main():
             result["cpu_baseline"] = cpu_baseline(wl, n_mels, sample)
         else:
             result["cpu_baseline"] = None
+        if world == 1 and not args.no_e2e and wl in ("whisper80", "resample_whisper"):
+            result["e2e"] = e2e_lines(wl, device, n_mels, sr, seed)
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

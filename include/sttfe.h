@@ -195,6 +195,12 @@ int sttfe_resample_plan_bytes(int orig_sr, int new_sr, size_t* bytes);
 int sttfe_resample_plan_build(int orig_sr, int new_sr, void* host_blob, size_t bytes);
 int sttfe_resample_plan_info(const void* host_blob, int* orig_rate, int* new_rate, int* width,
                              int* n_taps, int* taps_row);
+/* Zero-copy ingest: the device address of PAGE-LOCKED host memory (what a DataLoader with pin_memory=True hands over,
+ * reference src/config.py:77 / train.py:1457-1464), for use as `pcm_in` of sttfe_resample_peak / _s16: the kernel then
+ * pulls the clips' VALID samples over PCIe itself -- no staging copy of the padded (batch, n_max) tensor, padding never
+ * crosses the bus.  STTFE_E_UNSUPPORTED when the pointer is not mapped for the current device (pageable memory): copy
+ * it yourself then.  The caller keeps the host memory alive and unmodified until the work queued on `stream` is done. */
+int sttfe_host_mapped_pointer(const void* host_ptr, void** device_ptr);
 /* ceil(new * n_in / orig): the output length torchaudio crops to. */
 int sttfe_resample_out_length(int orig_sr, int new_sr, int64_t n_in, int64_t* n_out);
 

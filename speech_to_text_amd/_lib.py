@@ -51,6 +51,7 @@ def _declare(lib):
         "sttfe_resample_plan_build": [c_int, c_int, p, c_size_t],
         "sttfe_resample_plan_info": [p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)],
         "sttfe_resample_out_length": [c_int, c_int, c_int64, POINTER(c_int64)],
+        "sttfe_host_mapped_pointer": [p, POINTER(c_void_p)],
         "sttfe_preprocess_workspace_bytes": [c_int, POINTER(c_size_t)],
         "sttfe_resample_peak": [p, p, p, c_int, c_int, c_int64, p, p, p, p, p, p, c_size_t, p],
         "sttfe_resample_peak_s16": [p, p, p, c_int, c_int, c_int64, p, p, p, p, p, p, c_size_t, p],

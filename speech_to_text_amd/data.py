@@ -127,6 +127,8 @@ class GpuFrontEnd:
         # src/data.py:251-258: Speech2Text truncation limits come from the model config
         self.max_source_positions = max_source_positions
         self.max_target_positions = max_target_positions
+        self._ingest = None                  # same-rate copy / convert pass for pinned batches (zero-copy ingest)
+        self._held: List[Any] = []           # (event, pinned batch tensor) pairs still being read by the GPU
 
     @property
     def device(self) -> torch.device:
@@ -188,7 +190,6 @@ class GpuFrontEnd:
         device = self.device
         audio = batch["audio"]
         B, n_max = int(audio.shape[0]), int(audio.shape[-1])
-        pcm = audio.reshape(B, n_max).to(device=device, dtype=torch.float32, non_blocking=True).contiguous()
         if "audio_lengths" in batch:
             host_lengths = [int(v) for v in torch.as_tensor(batch["audio_lengths"]).tolist()]
         else:
@@ -196,7 +197,25 @@ class GpuFrontEnd:
         lengths = torch.tensor(host_lengths, dtype=torch.int32).to(device, non_blocking=True)
         offsets = (torch.arange(B, dtype=torch.int64) * n_max).to(device, non_blocking=True)
         texts = list(batch.get("texts", batch.get("text", [""] * B)))
-        pcm = pcm.reshape(-1)
+        if (audio.device.type == "cpu" and audio.is_pinned() and audio.is_contiguous()
+                and audio.dtype in (torch.float32, torch.int16) and audio.numel() == B * n_max):
+            # A pinned batch (DataLoader(pin_memory=True), src/config.py:77, train.py:1457-1464; float32 as the reference
+            # collates it, or int16 decoded PCM): the same-rate copy kernel pulls the clips' VALID samples over PCIe
+            # itself (sttfe_host_mapped_pointer) -- no H2D copy of the padded (B, n_max) tensor, whose padding is half
+            # of a Common-Voice batch, and no staging buffer.  The batch tensor is kept alive until the kernel is done.
+            if self._ingest is None:
+                from .preprocess import GpuAudioPreprocessor
+                self._ingest = GpuAudioPreprocessor(sample_rate=self.sample_rate, normalize=False, trim_silence=False,
+                                                    min_duration=0.0, max_duration=1e30, device=device)
+            p = self._ingest.run(audio.reshape(-1), offsets, lengths, host_lengths, 1, self.sample_rate,
+                                 sync_lengths=False, device=device)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+            self._held = [(e, t) for e, t in self._held if not e.query()] + [(ev, audio)]
+            pcm, offsets, lengths = p.pcm, p.offsets, p.lengths
+        else:
+            pcm = audio.reshape(B, n_max).to(device=device, dtype=torch.float32, non_blocking=True).contiguous()
+            pcm = pcm.reshape(-1)
         table = None
         if self.wave_sampler is not None and self.split == "train":
             # One clip after the other, as CommonVoiceDataset.__getitem__ does (src/data.py:328-329, :360-361):

@@ -263,7 +263,8 @@ class GpuAudioPreprocessor:
 
     def run(self, pcm_in: torch.Tensor, in_offsets: torch.Tensor, in_lengths: torch.Tensor,
             host_lengths: Sequence[int], channels: int, original_sample_rate: int,
-            sync_lengths: Optional[bool] = None, defer_normalize: bool = False) -> PackedAudio:
+            sync_lengths: Optional[bool] = None, defer_normalize: bool = False, copy: bool = False,
+            device: Optional[torch.device] = None) -> PackedAudio:
         """Device-resident entry: packed (planar) PCM at ``original_sample_rate`` -> PackedAudio at 16 kHz.
 
         ``defer_normalize`` (with ``normalize``): the samples are left unnormalised and ``PackedAudio.scale`` carries
@@ -280,8 +281,19 @@ class GpuAudioPreprocessor:
 
         ``sync_lengths`` (default: only when trimming) copies the trimmed lengths back to the host,
         which is what the duration gate and Speech2Text's dynamic padding need.
+
+        **Zero-copy ingest:** ``pcm_in`` may be a PINNED host tensor (``device=`` then names the GPU; offsets / lengths
+        are device tensors as always): the kernel reads the clips' valid samples over PCIe itself
+        (``sttfe_host_mapped_pointer``), so the padding of a collated ``(B, n_max)`` batch never crosses the bus and no
+        staging copy is made.  ``copy=True`` forces the packed copy for device input too (never aliases ``pcm_in``).
         """
-        device = pcm_in.device
+        host_in = pcm_in.device.type == "cpu"
+        if host_in:
+            if device is None or not pcm_in.is_pinned():
+                raise ValueError("host input must be pinned memory and needs device=")
+            device = torch.device(device)
+        else:
+            device = pcm_in.device
         L = _lib.lib()
         B = len(host_lengths)
         plan = self.plan(original_sample_rate)
@@ -293,7 +305,13 @@ class GpuAudioPreprocessor:
         s16 = pcm_in.dtype == torch.int16
         if not s16 and pcm_in.dtype != torch.float32:
             raise TypeError("packed PCM must be float32 or int16")
-        alias = plan is None and channels == 1 and not s16
+        alias = plan is None and channels == 1 and not s16 and not copy and not host_in
+        in_ptr = _lib.ptr(pcm_in)
+        if host_in:
+            mapped = ctypes.c_void_p()
+            with torch.cuda.device(device):
+                _lib.check(L.sttfe_host_mapped_pointer(in_ptr, ctypes.byref(mapped)), "sttfe_host_mapped_pointer")
+            in_ptr = mapped
         if alias:
             pcm_out, out_offsets = pcm_in, in_offsets.clone()
         else:
@@ -307,7 +325,7 @@ class GpuAudioPreprocessor:
         max_in = max(host_lengths) if B else 0
         with torch.cuda.device(device):
             entry = L.sttfe_resample_peak_s16 if s16 else L.sttfe_resample_peak
-            _lib.check(entry(_lib.ptr(pcm_in), _lib.ptr(in_offsets), _lib.ptr(in_lengths), B,
+            _lib.check(entry(in_ptr, _lib.ptr(in_offsets), _lib.ptr(in_lengths), B,
                              int(channels), int(max_in),
                              _lib.ptr(plan.on(device)) if plan else None,
                              _lib.ptr(plan.host) if plan else None,

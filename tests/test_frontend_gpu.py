@@ -192,3 +192,29 @@ def test_more_masks_than_the_old_limit_and_the_error_path():
     cfg, front = front_for(9, 8)                                       # 17 masks per clip
     with pytest.raises(_lib.SttfeError, match="invalid argument"):
         front(AudioCollator(cfg, "whisper")(samples))
+
+
+@pytest.mark.parametrize("split", ["train", "validation"])
+def test_pinned_batches_are_read_in_place_and_give_the_same_result(split):
+    """Round 3: a batch in pinned memory (DataLoader(pin_memory=True)) is not copied as a padded
+    (B, n_max) tensor -- the same-rate copy kernel reads the valid samples over PCIe.  Same features, masks and labels as
+    the pageable batch (same seeds), for float32; an int16 batch equals the float32 batch of x / 32768."""
+    clips, cfg, raw = raw_batch(33, [48000, 80000, 16000, 123457])
+    assert "audio_lengths" in raw
+    front = GpuFrontEnd(cfg, "whisper", False, tokenizer=FakeTokenizer(), split=split, device=DEV)
+
+    def run(batch):
+        torch.manual_seed(7)
+        random.seed(7)
+        return front(batch)
+
+    ref = run(raw)
+    pinned = dict(raw, audio=raw["audio"].pin_memory())
+    got = run(pinned)
+    assert torch.equal(got["input_features"], ref["input_features"]) and torch.equal(got["labels"], ref["labels"])
+    assert front._held and front._held[-1][1] is pinned["audio"]          # kept alive while the GPU reads it
+    s16 = torch.clamp(torch.round(raw["audio"] * 32767.0), -32768, 32767).to(torch.int16)
+    got16 = run(dict(raw, audio=s16.pin_memory()))
+    ref16 = run(dict(raw, audio=s16.to(torch.float32) / 32768.0))
+    assert torch.equal(got16["input_features"], ref16["input_features"])
+    torch.cuda.synchronize()

@@ -86,3 +86,32 @@ def test_pinned_ring_overlaps_and_matches_direct_path():
         assert got.host_lengths == exp.host_lengths
         for i in range(3):
             assert torch.equal(got.clip(i), exp.clip(i)), (k, i)
+
+
+@pytest.mark.parametrize("dtype,sr", [(np.float32, 16000), (np.int16, 16000), (np.float32, 48000), (np.int16, 48000)])
+def test_zero_copy_ingest_from_a_pinned_padded_batch(dtype, sr):
+    """Round 3: the collator's padded (B, n_max) batch in PINNED host memory (DataLoader pin_memory=True, reference
+    train.py:1457-1464) is read by the kernel itself over PCIe -- valid samples only, no staging copy
+    (sttfe_host_mapped_pointer).  Bit-identical to the same batch copied to the device first."""
+    from speech_to_text_amd.preprocess import GpuAudioPreprocessor
+    dev = torch.device(DEV)
+    lens = [sr // 3 + 1, 2 * sr + 5, 777, 4097, 1]
+    clips = s16_clips(sr, lens, 55)
+    if dtype == np.float32:
+        clips = [c.astype(np.float32) / np.float32(32768.0) for c in clips]
+    n_max = (max(lens) + 63) // 64 * 64
+    host = torch.zeros((len(lens), n_max), dtype=torch.from_numpy(clips[0]).dtype).pin_memory()
+    for i, c in enumerate(clips):
+        host[i, :len(c)] = torch.from_numpy(c)
+    offsets = (torch.arange(len(lens), dtype=torch.int64) * n_max).to(dev)
+    lengths = torch.tensor(lens, dtype=torch.int32, device=dev)
+    pre = GpuAudioPreprocessor(normalize=True, trim_silence=False, min_duration=0.0, max_duration=1e9, device=dev)
+    a = pre.run(host.reshape(-1), offsets, lengths, lens, 1, sr, device=dev)            # zero copy
+    b = pre.run(host.reshape(-1).to(dev), offsets, lengths, lens, 1, sr, copy=True)      # staged copy first
+    torch.cuda.synchronize()
+    assert a.host_lengths == b.host_lengths
+    for i in range(len(lens)):
+        assert torch.equal(a.clip(i), b.clip(i)), i
+    assert bool((host[0, lens[0]:] == 0).all())                                          # the batch itself is untouched
+    with pytest.raises(ValueError, match="pinned"):
+        pre.run(torch.zeros(64), offsets[:1], lengths[:1], [64], 1, sr, device=dev)      # pageable host memory

@@ -17,20 +17,27 @@ clips = synth_batch(7, lens)
 samples = [{"audio": torch.from_numpy(c)[None, :], "text": "t"} for c in clips]
 cfg = DataConfig(processing_and_augmentation_device="cuda", augmentation=AugmentationConfig(enabled=True))
 raw = AudioCollator(cfg, "whisper")(samples)
+raw["audio_lengths"] = torch.tensor(lens)
 front = GpuFrontEnd(cfg, "whisper", False, split="train", device="cuda:0", pitch_mode=pitch_mode)
-for _ in range(3):
-    front(raw)
-torch.cuda.synchronize()
-N = 10
-t0 = time.perf_counter()
-for _ in range(N):
-    out = front(raw)
-t_host = (time.perf_counter() - t0) / N          # the call returns when the host work is done
-torch.cuda.synchronize()
-t_all = (time.perf_counter() - t0) / N
 audio = float(sum(lens)) / 16000
-print(f"GpuFrontEnd, {B} Common-Voice-length clips ({audio:.0f} audio-s), all augmentations on, pitch_mode={pitch_mode}: "
-      f"{t_all * 1e3:.2f} ms per batch ({t_host * 1e3:.2f} ms until the call returns) -> {audio / t_all / 1e3:.1f} k audio-s/s", flush=True)
+pinned = dict(raw, audio=raw["audio"].pin_memory())                      # what DataLoader(pin_memory=True) hands over
+pinned16 = dict(raw, audio=torch.clamp(torch.round(raw["audio"] * 32767.0), -32768, 32767).to(torch.int16).pin_memory())
+for name, batch in (("pageable float32 batch", raw), ("pinned float32 batch (zero-copy ingest)", pinned),
+                    ("pinned int16 batch (zero-copy ingest)", pinned16)):
+    for _ in range(3):
+        front(batch)
+    torch.cuda.synchronize()
+    N = 10
+    t0 = time.perf_counter()
+    for _ in range(N):
+        out = front(batch)
+    t_host = (time.perf_counter() - t0) / N          # the call returns when the host work is done
+    torch.cuda.synchronize()
+    t_all = (time.perf_counter() - t0) / N
+    print(f"GpuFrontEnd, {B} Common-Voice-length clips ({audio:.0f} audio-s), all augmentations on, pitch_mode={pitch_mode}, "
+          f"{name}: {t_all * 1e3:.2f} ms per batch ({t_host * 1e3:.2f} ms until the call returns) -> "
+          f"{audio / t_all / 1e3:.1f} k audio-s/s", flush=True)
+raw = pinned
 try:
     import cProfile, pstats
     pr = cProfile.Profile()
