@@ -155,6 +155,39 @@ __global__ __launch_bounds__(256) void fill_j(float* out, const int* pad_frame, 
     }
 }
 
+// Flat line runs: the clip's fill lines -- per row the 128-byte lines that cover its padding
+// segment, rows in order -- are one sequence; every WAVE takes RUN consecutive lines of it, 8 lines (1 KB) per store
+// instruction, across row boundaries.  keep = 0: lanes outside the segment are masked (partial head / tail lines);
+// keep = 1: they read what is there and write it back (whole-line writes); keep = 2: head / tail lines left out.
+template <int RUN>
+__global__ __launch_bounds__(256) void fill_k(float* out, const int* pad_frame, int M, int T, int keep, size_t total_bytes) {
+    const int clip = blockIdx.y;
+    const int pf = pad_frame[clip];
+    const int L = ((T - pf) * 4 + 127) / 128 + 1;                          // lines per row (upper bound of the cover)
+    const int n_lines = M * L;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uintptr_t buf0 = reinterpret_cast<uintptr_t>(out), buf1 = buf0 + total_bytes;
+    const uintptr_t base = reinterpret_cast<uintptr_t>(out + (size_t)clip * M * T);
+    const int l0 = wave * RUN;
+#pragma unroll 4
+    for (int l = l0 + (lane >> 3); l < min(l0 + RUN, n_lines); l += 8) {
+        const int mel = l / L, k = l - mel * L;
+        const uintptr_t start = base + ((size_t)mel * T + pf) * 4, end = base + ((size_t)mel * T + T) * 4;
+        const uintptr_t a = (start & ~(uintptr_t)127) + 128 * (uintptr_t)k + 16 * (uintptr_t)(lane & 7);
+        const uintptr_t line = a & ~(uintptr_t)127;
+        if (line >= end) continue;
+        const bool inside = a >= start && a < end;
+        if (keep == 2) {
+            if (line >= start && line + 128 <= end) *reinterpret_cast<f32x4*>(a) = f32x4{-0.6f, -0.6f, -0.6f, -0.6f};
+        } else if (inside) {
+            *reinterpret_cast<f32x4*>(a) = f32x4{-0.6f, -0.6f, -0.6f, -0.6f};
+        } else if (keep == 1 && a >= buf0 && a + 16 <= buf1) {
+            const f32x4 val = *reinterpret_cast<const f32x4*>(a);
+            *reinterpret_cast<f32x4*>(a) = val;
+        }
+    }
+}
+
 // R consecutive rows per workgroup, TPB threads, rows written one after the other
 template <int R>
 __global__ void fill_e(float* out, const int* pad_frame, int M, int T) {
@@ -232,6 +265,20 @@ int main(int argc, char** argv) {
     for (int split : {16, 32}) {
         char nm[64]; snprintf(nm, 64, "J split=%d boundary lines first, then whole lines", split);
         time(nm, [&] { hipLaunchKernelGGL(fill_j, dim3(split, B), dim3(256), 0, 0, out, pf, M, T, (size_t)B * M * T * 4); });
+    }
+    {
+        int min_pf = 3000;
+        for (int v : h) min_pf = v < min_pf ? v : min_pf;
+        const int max_lines = M * (((T - min_pf) * 4 + 127) / 128 + 1);
+        for (int keep : {0, 1, 2}) {
+            char nm[80];
+            snprintf(nm, 80, "K run=32 lines per wave keep=%d", keep);
+            time(nm, [&] { hipLaunchKernelGGL(fill_k<32>, dim3((max_lines + 127) / 128, B), dim3(256), 0, 0, out, pf, M, T, keep, (size_t)B * M * T * 4); });
+            snprintf(nm, 80, "K run=80 lines per wave keep=%d", keep);
+            time(nm, [&] { hipLaunchKernelGGL(fill_k<80>, dim3((max_lines + 319) / 320, B), dim3(256), 0, 0, out, pf, M, T, keep, (size_t)B * M * T * 4); });
+            snprintf(nm, 80, "K run=320 lines per wave keep=%d", keep);
+            time(nm, [&] { hipLaunchKernelGGL(fill_k<320>, dim3((max_lines + 1279) / 1280, B), dim3(256), 0, 0, out, pf, M, T, keep, (size_t)B * M * T * 4); });
+        }
     }
     const size_t n4 = bytes / 16;
     for (int g : {1024, 4096, 16384, 65536}) {
