@@ -189,56 +189,41 @@ __device__ __forceinline__ bool plan_matches(const MelPlan& p) {
 //   kMask  : the clip has SpecAugment masks -- tbits = the tile's time-mask bits of frame tile FT (16), mbits = the
 //            clip's mel-mask bits of mel tile MT (16), both wave-uniform: a unit no mask touches (most of them) takes
 //            the plain stores after one scalar test, the others write 0.0 over the masked cells
-template <int NM, int MT>
-__device__ __forceinline__ void mel_unit_compute(const float* __restrict__ a_lane, const float* __restrict__ b_lane,
-                                            float mel_floor, float y_bias, float& run_max, float& tile_min,
-                                            float (&yv)[4]) {
+template <int NM, int MT, bool kMask>
+__device__ __forceinline__ void mel_unit_static(const float* __restrict__ a_lane, const float* __restrict__ b_lane,
+                                           float* __restrict__ out_u, unsigned (&o_r)[4], float mel_floor,
+                                           float y_bias, float& run_max, float& tile_min, unsigned tbits, unsigned mbits,
+                                           int lane) {
     using P = wh::StaticPlan<NM>;
     constexpr int KS = P::kstart[MT], NG = P::nsteps[MT] / 4, AO = P::aoff[MT];
     const f32x4* __restrict__ a = reinterpret_cast<const f32x4*>(a_lane + AO);
     const f32x4* __restrict__ b = reinterpret_cast<const f32x4*>(b_lane + KS);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-    // All operand reads of the unit are requested before its first MFMA (the registers of the transform are free here).
-    f32x4 av[NG], bv[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        av[g] = a[g * 64];
-        bv[g] = b[4 * g];
-    }
-    __builtin_amdgcn_sched_barrier(0);
+        const f32x4 av = a[g * 64], bv = b[4 * g];
 #if STTFE_FLOOR == 4 || STTFE_FLOOR == 6
-    // floor build: the operand reads stay, the matrix instructions are replaced by one packed multiply-add per group
-#pragma unroll
-    for (int g = 0; g < NG; ++g) acc += av[g] * bv[g];
+        acc += av * bv;                                               // floor build: operand reads without the MFMAs
 #else
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][0], bv[g][0], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][1], bv[g][1], acc2, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][2], bv[g][2], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][3], bv[g][3], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc2, 0, 0, 0);
+#endif
     }
     acc += acc2;
-#endif
-    float mv[4];
+    float mv[4], yv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         mv[r] = fmaxf(acc[r], mel_floor);
         yv[r] = fmaf(__log2f(mv[r]), 0.25f * 0.30102999566398120f, y_bias);
     }
-    // max / min count the masked cells too: the masks are applied to the finished features (src/data.py:185-194)
-    run_max = fmaxf(fmaxf(run_max, fmaxf(mv[0], mv[1])), fmaxf(mv[2], mv[3]));
-    tile_min = fminf(fminf(tile_min, fminf(mv[0], mv[1])), fminf(mv[2], mv[3]));
-}
-
-template <bool kMask>
-__device__ __forceinline__ void mel_unit_store(float* __restrict__ out_u, unsigned (&o_r)[4], const float (&yv)[4],
-                                          unsigned tbits, unsigned mbits, int lane) {
-#if STTFE_FLOOR == 7
-    return;                                                           // floor build: no feature stores
-#endif
 #pragma unroll                                                        // opaque in place: the zero-extension then stays beside
     for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(o_r[r]));      // the store, which takes scalar base + 32-bit lane offset
+#if STTFE_FLOOR == 7
+    run_max = fmaxf(run_max, (yv[0] + yv[1]) + (yv[2] + yv[3]));      // floor build: no feature stores
+    return;
+#endif
     if (kMask && (tbits | mbits) != 0u) {                             // wave-uniform
         const bool tmasked = (tbits >> (lane & 15)) & 1u;
         const unsigned mb = (mbits >> ((lane >> 4) * 4)) & 15u;
@@ -249,6 +234,9 @@ __device__ __forceinline__ void mel_unit_store(float* __restrict__ out_u, unsign
 #pragma unroll
         for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(reinterpret_cast<char*>(out_u) + o_r[r]) = yv[r];
     }
+    // max / min count the masked cells too: the masks are applied to the finished features (src/data.py:185-194)
+    run_max = fmaxf(fmaxf(run_max, fmaxf(mv[0], mv[1])), fmaxf(mv[2], mv[3]));
+    tile_min = fminf(fminf(tile_min, fminf(mv[0], mv[1])), fminf(mv[2], mv[3]));
 }
 
 // First frame (a multiple of 4) from which every cell of a clip is the padding constant.  Zero padding to 30 s: frame t
@@ -503,14 +491,14 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     };
     float raw0[28], raw1[28];                      // the two passes of the NEXT tile, loaded a whole tile ahead
 #if STTFE_FLOOR
-    // Floor builds (tools/ubench/whisper_floor.py): the same kernel with phases left out.
+    // Floor builds (tools/ubench/whisper_floor.py): the same kernel with phases left out; all but
+    // the shipped build (0) give wrong features and exist for timing only.
     //   1: the transform alone -- no PCM loads, no power panel, no barriers, no mel projection, no stores
     //   2: PCM loads + transform (no panel, barriers, mel, stores)
     //   3: everything but the transform (the power values are copies of the samples)
     //   4: the whole kernel with the mel projection's MFMAs replaced by one packed multiply-add per operand pair
     //   5: the whole kernel without the two workgroup barriers of the tile loop;  6: both 4 and 5
     //   7: the whole kernel without the feature stores;  8: without the mel phase (operand reads, MFMAs, epilogue, stores)
-    //   (4 - 8 give wrong features: timing only)
     f2 floor_sink = {0.0f, 0.0f};
 #pragma unroll
     for (int m = 0; m < 28; ++m) {
@@ -709,34 +697,12 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
           load_pass(x, n_valid, tile_begin * kTileFrames, 1, raw1);
       }
       raw_ready = false;
-      // (every path into the tile loop and around it leaves the sample registers settled -- here, and before the feature
-      // stores of a tile: with one path on which they are still in flight the compiler guards the top of the loop with
-      // s_waitcnt vmcnt(0), which on the way round waits for the previous tile's stores)
-      asm volatile("" ::"v"(raw1[27]), "v"(raw0[27]));
       float run_max = 0.0f;                         // mel energies (>= 1e-10 once any cell was produced)
       for (int tile = tile_begin; tile < tile_end; ++tile) {
         const int t0 = tile * kTileFrames;
 #ifdef STTFE_STAMPS
         if (tile == tile_begin) STAMP(11);
 #endif
-        // next tile's PCM -- of this item, or the first tile of the workgroup's next item -- requested pass by pass as
-        // soon as the first-stage arithmetic has consumed the registers
-        auto prefetch_pass = [&](int pass, float (&r)[28]) {
-            if (tile + 1 < tile_end) {
-                load_pass(x, n_valid, t0 + kTileFrames, pass, r);
-            } else if (next_item < n_items) {
-                int nv = clamp_len(__builtin_amdgcn_readfirstlane(len_next)), tb = __builtin_amdgcn_readfirstlane(run_nx * tiles_per_block);
-                asm volatile("" : "+v"(nv), "+v"(tb));
-                nv = __builtin_amdgcn_readfirstlane(nv);
-                tb = __builtin_amdgcn_readfirstlane(tb);
-                const int64_t off_n = ((int64_t)__builtin_amdgcn_readfirstlane((int)(off_next >> 32)) << 32) |
-                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)off_next);
-                if (tb < min(n_tiles, first_pad_tile_of(nv))) {
-                    load_pass(pcm + off_n, nv, tb * kTileFrames, pass, r);
-                    raw_ready = true;
-                }
-            }
-        };
         {
             f2 ya[20], yb[20], pw0[11], pw1[11], q0[10], q1[10];
             f32x4 ra[10], rb[10];
@@ -751,11 +717,9 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
             store_rows(1, pw1);
 #else
             s1_math(raw0, ya);
-            prefetch_pass(0, raw0);
             s1_write(ya);
             s2_read(ra);                       // pass 0 rows in flight ...
             s1_math(raw1, yb);                 // ... under the first-stage arithmetic of pass 1
-            prefetch_pass(1, raw1);
             STAMP(0);
             s1_write(yb);                      // LDS runs a wave's operations in order: after the reads above
             s2_read(rb);
@@ -780,6 +744,24 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         }
         // next tile's PCM -- of this item, or the first tile of the workgroup's next item: issued now (few live
         // registers from here on), lands during the mel projection
+        if (tile + 1 < tile_end) {
+            load_pass(x, n_valid, t0 + kTileFrames, 0, raw0);
+            load_pass(x, n_valid, t0 + kTileFrames, 1, raw1);
+        } else if (next_item < n_items) {
+            // (the empty asm makes these values opaque here: otherwise the compiler computes the 56 load indices and
+            // bounds predicates of the next item at the top of this item and spills them across the whole tile loop)
+            int nv = clamp_len(__builtin_amdgcn_readfirstlane(len_next)), tb = __builtin_amdgcn_readfirstlane(run_nx * tiles_per_block);
+            asm volatile("" : "+v"(nv), "+v"(tb));
+            nv = __builtin_amdgcn_readfirstlane(nv);
+            tb = __builtin_amdgcn_readfirstlane(tb);
+            const int64_t off_n = ((int64_t)__builtin_amdgcn_readfirstlane((int)(off_next >> 32)) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)off_next);
+            if (tb < min(n_tiles, first_pad_tile_of(nv))) {
+                load_pass(pcm + off_n, nv, tb * kTileFrames, 0, raw0);
+                load_pass(pcm + off_n, nv, tb * kTileFrames, 1, raw1);
+                raw_ready = true;
+            }
+        }
 #if STTFE_FLOOR == 1 || STTFE_FLOOR == 2
         continue;
 #endif
@@ -815,54 +797,68 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
             const float* b1 = smem + brow1;
             const float* b2 = smem + brow2;
             const size_t nf16 = (size_t)16 * n_frames;
-            // Every unit's features stay in registers until the wave has waited for the next tile's samples (requested
-            // before the barrier above); only then are the stores issued.  s_waitcnt counts loads and stores together,
-            // in order, and the compiler cannot know how many stores lie between the sample loads and their first use at
-            // the top of the next tile (the paths differ), so with stores issued unit by unit the transform of the next
-            // tile began with s_waitcnt vmcnt(0): every store of this tile acknowledged by L2 first -- 12 % of the kernel
-            // (tools/ubench/whisper_floor.py, floor 7).  This way the stores drain under the next tile's transform.
-            float yv[6][4];
-#define STTFE_C(I, NM, MT, FT) mel_unit_compute<NM, MT>(a_lane, b##FT, mel_floor, y_bias, run_max, tile_min, yv[I]);
-#define STTFE_S(MASKED, I, NM, MT, FT)                                                                                \
-    mel_unit_store<MASKED>(ob + MT * nf16 + FT * 16, o_r, yv[I], (unsigned)(tmask >> (FT * 16)) & 0xffffu,             \
-                                 (unsigned)((MT < 4 ? melmask_lo : melmask_hi) >> ((MT & 3) * 16)) & 0xffffu, lane);
-#define STTFE_U80_0(X) X(0, 80, 4, 0) X(1, 80, 3, 2) X(2, 80, 2, 2)
-#define STTFE_U80_1(X) X(0, 80, 4, 1) X(1, 80, 1, 0) X(2, 80, 1, 1) X(3, 80, 0, 0)
-#define STTFE_U80_2(X) X(0, 80, 4, 2) X(1, 80, 2, 0) X(2, 80, 2, 1) X(3, 80, 0, 1)
-#define STTFE_U80_3(X) X(0, 80, 3, 0) X(1, 80, 3, 1) X(2, 80, 1, 2) X(3, 80, 0, 2)
-#define STTFE_U128_0(X) X(0, 128, 7, 0) X(1, 128, 5, 1) X(2, 128, 4, 0) X(3, 128, 1, 0) X(4, 128, 1, 1) X(5, 128, 1, 2)
-#define STTFE_U128_1(X) X(0, 128, 7, 1) X(1, 128, 6, 1) X(2, 128, 4, 1) X(3, 128, 2, 0) X(4, 128, 2, 1) X(5, 128, 2, 2)
-#define STTFE_U128_2(X) X(0, 128, 7, 2) X(1, 128, 5, 2) X(2, 128, 4, 2) X(3, 128, 3, 0) X(4, 128, 3, 1) X(5, 128, 3, 2)
-#define STTFE_U128_3(X) X(0, 128, 5, 0) X(1, 128, 6, 0) X(2, 128, 6, 2) X(3, 128, 0, 0) X(4, 128, 0, 1) X(5, 128, 0, 2)
-            // the use of the youngest sample load places the wait: the counter is in order, so it covers every older load
-#define STTFE_WAVE_UNITS(LIST)                                        \
-    {                                                                 \
-        LIST(STTFE_C)                                                 \
-        asm volatile("" ::"v"(raw1[27]), "v"(raw0[27]));              \
-        if (nm == 0) {                                                \
-            LIST(STTFE_SU)                                            \
-        } else {                                                      \
-            LIST(STTFE_SM)                                            \
-        }                                                             \
-    }
-#define STTFE_SU(I, NM, MT, FT) STTFE_S(false, I, NM, MT, FT)
-#define STTFE_SM(I, NM, MT, FT) STTFE_S(true, I, NM, MT, FT)
+#define STTFE_U(NM, MT, FT) \
+    mel_unit_static<NM, MT, STTFE_MASKED>(a_lane, b##FT, ob + MT * nf16 + FT * 16, o_r, mel_floor, y_bias, run_max, tile_min, \
+                                          (unsigned)(tmask >> (FT * 16)) & 0xffffu,                                     \
+                                          (unsigned)((MT < 4 ? melmask_lo : melmask_hi) >> ((MT & 3) * 16)) & 0xffffu, lane)
+            if (nm == 0) {
+#define STTFE_MASKED false
             if (static_plan == 80) {
-                if (wave == 0) STTFE_WAVE_UNITS(STTFE_U80_0)
-                else if (wave == 1) STTFE_WAVE_UNITS(STTFE_U80_1)
-                else if (wave == 2) STTFE_WAVE_UNITS(STTFE_U80_2)
-                else STTFE_WAVE_UNITS(STTFE_U80_3)
+                if (wave == 0) {
+                    STTFE_U(80, 4, 0); STTFE_U(80, 3, 2); STTFE_U(80, 2, 2);
+                } else if (wave == 1) {
+                    STTFE_U(80, 4, 1); STTFE_U(80, 1, 0); STTFE_U(80, 1, 1); STTFE_U(80, 0, 0);
+                } else if (wave == 2) {
+                    STTFE_U(80, 4, 2); STTFE_U(80, 2, 0); STTFE_U(80, 2, 1); STTFE_U(80, 0, 1);
+                } else {
+                    STTFE_U(80, 3, 0); STTFE_U(80, 3, 1); STTFE_U(80, 1, 2); STTFE_U(80, 0, 2);
+                }
             } else {
-                if (wave == 0) STTFE_WAVE_UNITS(STTFE_U128_0)
-                else if (wave == 1) STTFE_WAVE_UNITS(STTFE_U128_1)
-                else if (wave == 2) STTFE_WAVE_UNITS(STTFE_U128_2)
-                else STTFE_WAVE_UNITS(STTFE_U128_3)
+                if (wave == 0) {
+                    STTFE_U(128, 7, 0); STTFE_U(128, 5, 1); STTFE_U(128, 4, 0);
+                    STTFE_U(128, 1, 0); STTFE_U(128, 1, 1); STTFE_U(128, 1, 2);
+                } else if (wave == 1) {
+                    STTFE_U(128, 7, 1); STTFE_U(128, 6, 1); STTFE_U(128, 4, 1);
+                    STTFE_U(128, 2, 0); STTFE_U(128, 2, 1); STTFE_U(128, 2, 2);
+                } else if (wave == 2) {
+                    STTFE_U(128, 7, 2); STTFE_U(128, 5, 2); STTFE_U(128, 4, 2);
+                    STTFE_U(128, 3, 0); STTFE_U(128, 3, 1); STTFE_U(128, 3, 2);
+                } else {
+                    STTFE_U(128, 5, 0); STTFE_U(128, 6, 0); STTFE_U(128, 6, 2);
+                    STTFE_U(128, 0, 0); STTFE_U(128, 0, 1); STTFE_U(128, 0, 2);
+                }
             }
-#undef STTFE_WAVE_UNITS
-#undef STTFE_SU
-#undef STTFE_SM
-#undef STTFE_C
-#undef STTFE_S
+#undef STTFE_MASKED
+            } else {
+#define STTFE_MASKED true
+            if (static_plan == 80) {
+                if (wave == 0) {
+                    STTFE_U(80, 4, 0); STTFE_U(80, 3, 2); STTFE_U(80, 2, 2);
+                } else if (wave == 1) {
+                    STTFE_U(80, 4, 1); STTFE_U(80, 1, 0); STTFE_U(80, 1, 1); STTFE_U(80, 0, 0);
+                } else if (wave == 2) {
+                    STTFE_U(80, 4, 2); STTFE_U(80, 2, 0); STTFE_U(80, 2, 1); STTFE_U(80, 0, 1);
+                } else {
+                    STTFE_U(80, 3, 0); STTFE_U(80, 3, 1); STTFE_U(80, 1, 2); STTFE_U(80, 0, 2);
+                }
+            } else {
+                if (wave == 0) {
+                    STTFE_U(128, 7, 0); STTFE_U(128, 5, 1); STTFE_U(128, 4, 0);
+                    STTFE_U(128, 1, 0); STTFE_U(128, 1, 1); STTFE_U(128, 1, 2);
+                } else if (wave == 1) {
+                    STTFE_U(128, 7, 1); STTFE_U(128, 6, 1); STTFE_U(128, 4, 1);
+                    STTFE_U(128, 2, 0); STTFE_U(128, 2, 1); STTFE_U(128, 2, 2);
+                } else if (wave == 2) {
+                    STTFE_U(128, 7, 2); STTFE_U(128, 5, 2); STTFE_U(128, 4, 2);
+                    STTFE_U(128, 3, 0); STTFE_U(128, 3, 1); STTFE_U(128, 3, 2);
+                } else {
+                    STTFE_U(128, 5, 0); STTFE_U(128, 6, 0); STTFE_U(128, 6, 2);
+                    STTFE_U(128, 0, 0); STTFE_U(128, 0, 1); STTFE_U(128, 0, 2);
+                }
+            }
+#undef STTFE_MASKED
+            }
+#undef STTFE_U
         } else {
 #if STTFE_FLOOR == 8
         const int nu = 0;                                           // floor build: no mel projection at all
@@ -946,7 +942,6 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
             STAMP(1);
         }
         }   // generic unit loop
-        asm volatile("" ::"v"(raw1[27]), "v"(raw0[27]));               // (generic path: see the static one)
         // per-tile minimum (kernel 2 re-reads only the tiles that hold something below max - 8)
         tile_min = wave_min(tile_min);
         if (lane == 0 && tile_min < 1.0e38f && tile < kMaxTiles)       // (tiles behind the output have no min key: not stored)
