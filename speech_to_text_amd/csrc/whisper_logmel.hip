@@ -185,13 +185,13 @@ __device__ __forceinline__ bool plan_matches(const MelPlan& p) {
 
 // One (mel tile MT, frame tile FT) unit of a whole 48-frame tile of an NM-bin extractor.
 //   a_lane : this lane's A-operand base (mel weights, LDS), b_lane : its B-operand row base of frame tile FT (panel)
-//   out_u  : scalar pointer out_clip + t0 + MT * 16 * n_frames + FT * 16;  o_q : per-lane byte offset of its four frames
+//   out_u  : scalar pointer out_clip + t0 + MT * 16 * n_frames + FT * 16;  o_r : per-lane store offsets, r = 0..3
 //   kMask  : the clip has SpecAugment masks -- tbits = the tile's time-mask bits of frame tile FT (16), mbits = the
 //            clip's mel-mask bits of mel tile MT (16), both wave-uniform: a unit no mask touches (most of them) takes
 //            the plain stores after one scalar test, the others write 0.0 over the masked cells
 template <int NM, int MT, bool kMask>
 __device__ __forceinline__ void mel_unit_static(const float* __restrict__ a_lane, const float* __restrict__ b_lane,
-                                           float* __restrict__ out_u, unsigned o_q, float mel_floor,
+                                           float* __restrict__ out_u, unsigned (&o_r)[4], float mel_floor,
                                            float y_bias, float& run_max, float& tile_min, unsigned tbits, unsigned mbits,
                                            int lane) {
     using P = wh::StaticPlan<NM>;
@@ -205,12 +205,10 @@ __device__ __forceinline__ void mel_unit_static(const float* __restrict__ a_lane
 #if STTFE_FLOOR == 4 || STTFE_FLOOR == 6
         acc += av * bv;                                               // floor build: operand reads without the MFMAs
 #else
-        // (frames as the rows of the product: lane l ends up with frames 4 (l >> 4) .. + 3 of mel bin l & 15, one
-        // 16-byte store instead of four 4-byte ones -- a dword store costs the address unit as many cycles as a b128 one)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[0], av[0], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[1], av[1], acc2, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[2], av[2], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[3], av[3], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc2, 0, 0, 0);
 #endif
     }
     acc += acc2;
@@ -220,15 +218,21 @@ __device__ __forceinline__ void mel_unit_static(const float* __restrict__ a_lane
         mv[r] = fmaxf(acc[r], mel_floor);
         yv[r] = fmaf(__log2f(mv[r]), 0.25f * 0.30102999566398120f, y_bias);
     }
-    asm volatile("" : "+v"(o_q));                                     // opaque in place: the zero-extension then stays beside
-    f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(out_u) + o_q);   // the store (scalar base + 32-bit lane offset)
+#pragma unroll                                                        // opaque in place: the zero-extension then stays beside
+    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(o_r[r]));      // the store, which takes scalar base + 32-bit lane offset
+#if STTFE_FLOOR == 7
+    run_max = fmaxf(run_max, (yv[0] + yv[1]) + (yv[2] + yv[3]));      // floor build: no feature stores
+    return;
+#endif
     if (kMask && (tbits | mbits) != 0u) {                             // wave-uniform
-        const bool mmasked = (mbits >> (lane & 15)) & 1u;
-        const unsigned tb = (tbits >> ((lane >> 4) * 4)) & 15u;
-        *dst = f32x4{(mmasked || (tb & 1u)) ? 0.0f : yv[0], (mmasked || (tb & 2u)) ? 0.0f : yv[1],
-                     (mmasked || (tb & 4u)) ? 0.0f : yv[2], (mmasked || (tb & 8u)) ? 0.0f : yv[3]};
+        const bool tmasked = (tbits >> (lane & 15)) & 1u;
+        const unsigned mb = (mbits >> ((lane >> 4) * 4)) & 15u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(out_u) + o_r[r]) = (tmasked || ((mb >> r) & 1u)) ? 0.0f : yv[r];
     } else {
-        *dst = f32x4{yv[0], yv[1], yv[2], yv[3]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(reinterpret_cast<char*>(out_u) + o_r[r]) = yv[r];
     }
     // max / min count the masked cells too: the masks are applied to the finished features (src/data.py:185-194)
     run_max = fmaxf(fmaxf(run_max, fmaxf(mv[0], mv[1])), fmaxf(mv[2], mv[3]));
@@ -639,11 +643,10 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     const int static_plan = __builtin_amdgcn_readfirstlane(
         n_mels == 80 && plan_matches<80>(tab->plan) ? 80 : (n_mels == 128 && plan_matches<128>(tab->plan) ? 128 : 0));
     const float* a_lane = smem + kAfragOff + 4 * lane;
-    // (the static units store 16 bytes per lane: rows of a multiple of 4 frames in a 16-byte aligned tensor)
-    const bool stores_aligned = __builtin_amdgcn_readfirstlane(
-        ((n_frames & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) ? 1 : 0);
-    // BYTES: a 32-bit lane offset beside the unit's scalar base is the store's own addressing mode (no 64-bit add per store)
-    const unsigned o_q = 4u * (unsigned)((lane & 15) * n_frames + (lane >> 4) * 4);
+    unsigned o_r[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o_r[r] = 4u * (unsigned)(((lane >> 4) * 4 + r) * n_frames + (lane & 15));   // BYTES: a 32-bit
+    // lane offset beside the unit's scalar base is the store's own addressing mode (no 64-bit add per store)
 #ifdef STTFE_STAMPS
     // slots 0-9: phases of the tile loop; 10: kernel entry -> item loop; 11: item switches (end of an item's last tile
     // -> start of the next item's first tile, empty items included); 12: after the last item; 13 / 14: entry / exit time;
@@ -785,7 +788,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 #if STTFE_FLOOR == 8
         if (false) {
 #else
-        if (static_plan != 0 && stores_aligned && t0 + kTileFrames <= min(min(n_frames, key_frames), const_frame)) {
+        if (static_plan != 0 && t0 + kTileFrames <= min(min(n_frames, key_frames), const_frame)) {
 #endif
             // whole tile of an 80- or 128-bin extractor: the wave's units from the static plan (the same assignment
             // as tables.cpp's: 48 / 44 / 44 / 44 k-steps per wave for 80 bins, 52 / 52 / 52 / 48 for 128)
@@ -795,7 +798,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
             const float* b2 = smem + brow2;
             const size_t nf16 = (size_t)16 * n_frames;
 #define STTFE_U(NM, MT, FT) \
-    mel_unit_static<NM, MT, STTFE_MASKED>(a_lane, b##FT, ob + MT * nf16 + FT * 16, o_q, mel_floor, y_bias, run_max, tile_min, \
+    mel_unit_static<NM, MT, STTFE_MASKED>(a_lane, b##FT, ob + MT * nf16 + FT * 16, o_r, mel_floor, y_bias, run_max, tile_min, \
                                           (unsigned)(tmask >> (FT * 16)) & 0xffffu,                                     \
                                           (unsigned)((MT < 4 ? melmask_lo : melmask_hi) >> ((MT & 3) * 16)) & 0xffffu, lane)
             if (nm == 0) {
