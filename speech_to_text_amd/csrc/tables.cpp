@@ -265,16 +265,12 @@ static int kaldi_tables(int n_mels, std::vector<unsigned char>& blob) {
                     lo = std::min(lo, k);
                     hi = std::max(hi, k);
                 }
-            // bands are padded to a multiple of four bins with zero weights (the kernel's band loop takes four bins per
-            // trip and has no remainder loop; a zero weight adds +0.0 to the sum: bit-identical), never past bin 256
-            const int cnt = hi >= lo ? (hi - lo + 1 + 3) / 4 * 4 : 0;
-            const int start = hi >= lo ? std::max(0, std::min(lo, 257 - cnt)) : 0;
-            band[4 * m] = start;
-            band[4 * m + 1] = cnt;
+            band[4 * m] = hi >= lo ? lo : 0;
+            band[4 * m + 1] = hi >= lo ? hi - lo + 1 : 0;
             band[4 * m + 2] = (int32_t)wts.size();
-            for (int k = start; k < start + cnt; ++k) wts.push_back(k < 257 ? w64[(size_t)m * 257 + k] * 268435456.0 : 0.0);
+            for (int k = lo; k <= hi; ++k) wts.push_back(w64[(size_t)m * 257 + k] * 268435456.0);
         }
-        h.reserved = (int32_t)wts.size();          // number of float64 band weights (<= 2 per FFT bin + 3 per mel bin of padding)
+        h.reserved = (int32_t)wts.size();          // number of float64 band weights (<= 2 per FFT bin)
         const size_t base = t64.size();
         t64.resize(base + 2 * (size_t)n_mels + wts.size());
         std::memcpy(&t64[base], band.data(), band.size() * sizeof(int32_t));
