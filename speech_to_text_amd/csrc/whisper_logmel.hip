@@ -86,7 +86,7 @@ constexpr int kMaskOff = kTicketOff + 4;              // the current clip's Spec
 constexpr int kPlanOff = kMaskOff + 3 * STTFE_MAX_MASKS;      // ragged batches: exclusive prefix of the clips' run counts
 constexpr int kMaxPlanClips = 3072;                   // (12 KB; larger batches keep the dense run x clip item space)
 constexpr int kLdsFloats = kPlanOff + kMaxPlanClips + 1;   // ~77 KB -> 2 workgroups per CU
-constexpr int kFuseSplit = 4;                         // fused clamp / fill: items (blocks of mel rows) per clip
+constexpr int kFuseSplit = 4;                         // fused padding fill: items (blocks of mel rows) per clip
 constexpr int kFillSpinLimit = 1 << 19;               // polls (~1 us each) a fill item waits for its clip before it goes ahead anyway
 }  // namespace wh
 
@@ -195,7 +195,7 @@ template <int NM, int MT, bool kMask>
 __device__ __forceinline__ void mel_unit_static(const float* __restrict__ a_lane, const float* __restrict__ b_lane,
                                            float* __restrict__ out_u, unsigned (&o_r)[4], float mel_floor,
                                            float y_bias, float& run_max, float& tile_min, unsigned tbits, unsigned mbits,
-                                           int lane, bool wt) {
+                                           int lane) {
     using P = wh::StaticPlan<NM>;
     constexpr int KS = P::kstart[MT], NG = P::nsteps[MT] / 4, AO = P::aoff[MT];
     const f32x4* __restrict__ a = reinterpret_cast<const f32x4*>(a_lane + AO);
@@ -230,13 +230,8 @@ __device__ __forceinline__ void mel_unit_static(const float* __restrict__ a_lane
         const bool tmasked = (tbits >> (lane & 15)) & 1u;
         const unsigned mb = (mbits >> ((lane >> 4) * 4)) & 15u;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) yv[r] = (tmasked || ((mb >> r) & 1u)) ? 0.0f : yv[r];
-    }
-    if (wt) {                                                         // wave-uniform: fused fill, see kernel 1
-#pragma unroll
         for (int r = 0; r < 4; ++r)
-            __hip_atomic_store(reinterpret_cast<float*>(reinterpret_cast<char*>(out_u) + o_r[r]), yv[r], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(out_u) + o_r[r]) = (tmasked || ((mb >> r) & 1u)) ? 0.0f : yv[r];
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(reinterpret_cast<char*>(out_u) + o_r[r]) = yv[r];
@@ -258,198 +253,22 @@ __device__ __forceinline__ int whisper_const_frame(int n_valid, int n_frames, in
     return min(min(f, tile_pad_frame), n_frames);
 }
 
-// Clamp / fill pass (whisper_clamp_fill_kernel: grid.x = row split, grid.y = clips; workgroup x owns one block of mel rows).
-//   fill : the clip's zero-padding region [first padding frame, n_frames) gets the final constant with full-row
-//          vector stores (kernel 1 never touches it);
-//   clamp: of the computed tiles only those whose recorded minimum is below max - 8 (a few per cent of the tiles of
-//          ordinary audio; none for most clips) are re-read and clamped to (max - 8 + 4) / 4.
-// SpecAugment masks -> 0.0 on everything written.
-// The clamp / fill work of one (clip, block of mel rows): the body of whisper_clamp_fill_kernel, also run by kernel 1
-// itself as a work item of its own (ragged batches, see "fused" there).  256 threads; every thread of the workgroup
-// calls it with the same arguments.
-struct ClampFillLds {
-    unsigned long long flags;
-    int32_t masks[3 * STTFE_MAX_MASKS];
-    unsigned char tiles[64];
+// The constant of a clip's padding region (kernel 2, and the fused fill items of kernel 1), from the clip's max key.
+// Scaled clips (see kernel 1): keys are log10 of the unscaled energies, stored values carry the bias c / 4 with
+// c = 2 log10(s); the zero padding is log10(1e-10) = -10 in the scaled domain, i.e. -10 - c in the keys' domain.
+struct WhisperFloor {
+    float floor_lg, floor_y, pad_y;
 };
-template <bool kSameLaunch>       // called inside kernel 1: keys come through device-coherent loads (never the scalar cache)
-__device__ __forceinline__ void whisper_clamp_fill_rows(
-    float* __restrict__ out, const int32_t* __restrict__ lengths, const unsigned* __restrict__ keys,
-    int n_mels, int n_frames, const int32_t* __restrict__ mask_tbl, int n_masks,
-    const float* __restrict__ clip_scale, int mode, float pad_value, int clip, int row0, int row_step,
-    ClampFillLds& lds) {
-    using namespace wh;
-    // Everything the workgroup needs from memory is requested in ONE batch (length, max key, the per-tile min keys,
-    // the clip's mask table -> LDS): with four dependent round trips per workgroup this kernel was latency-bound
-    // (0.10 ms for 32 k workgroups that find nothing to clamp).
-    unsigned long long& s_flags = lds.flags;
-    int32_t* s_masks = lds.masks;
-    const int nm = mask_tbl ? n_masks : 0;
-    int n_valid = lengths[clip];
-    auto key_at = [&](size_t i) {
-        return kSameLaunch ? __hip_atomic_load(keys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : keys[i];
-    };
-    const unsigned kmax = key_at((size_t)clip * kKeysPerClip);
-    unsigned kmin_raw = 0xffffffffu;
-    if (threadIdx.x < kKeysPerClip - 1) kmin_raw = key_at((size_t)clip * kKeysPerClip + 1 + threadIdx.x);
-    if ((int)threadIdx.x < 3 * nm) s_masks[threadIdx.x] = mask_tbl[(size_t)clip * n_masks * 3 + threadIdx.x];
-    const int len_cap = mode == kModeTorchVarlen ? kVarMaxSamples : kMaxSamples;
-    n_valid = n_valid < 0 ? 0 : (n_valid > len_cap ? len_cap : n_valid);
-    const int n_tiles = (n_frames + kTileFrames - 1) / kTileFrames;
-    const int first_pad_tile = min(n_tiles, mode == kModeTorchVarlen
-                                                ? (1 + n_valid / kHop + kTileFrames - 1) / kTileFrames
-                                                : (n_valid + kNfft / 2 + kHop * kTileFrames - 1) / (kHop * kTileFrames));
-    // first frame of the constant region (a multiple of 4)
-    const int pad_frame = whisper_const_frame(n_valid, n_frames, min(n_frames, first_pad_tile * kTileFrames), mode);
-    const int key_frames = mode == kModeTorchVarlen ? 1 + n_valid / kHop : n_frames;   // frames that hold data
-    // scaled clips (see kernel 1): keys are log10 of the unscaled energies, stored values carry the bias c / 4 with
-    // c = 2 log10(s); the zero padding is log10(1e-10) = -10 in the scaled domain, i.e. -10 - c in the keys' domain
+__device__ __forceinline__ WhisperFloor whisper_floor(unsigned kmax, const float* __restrict__ clip_scale, int clip, int mode,
+                                                      float pad_value) {
     const float c_lg = clip_scale ? 2.0f * 0.30102999566398120f * __log2f(clip_scale[clip]) : 0.0f;
     const float lmax = kmax ? key_to_float(kmax) : -10.0f - c_lg; // no computed tile at all: the floor itself
-    const float floor_lg = lmax - 8.0f;
-    const float floor_y = (floor_lg + 4.0f) * 0.25f + 0.25f * c_lg;
+    WhisperFloor f;
+    f.floor_lg = lmax - 8.0f;
+    f.floor_y = (f.floor_lg + 4.0f) * 0.25f + 0.25f * c_lg;
     // zero padding to 30 s: log10(1e-10) clamped like everything else; variable-length mode: the literal padding_value
-    const float pad_y = mode == kModeTorchVarlen ? pad_value : fmaxf((-10.0f + 4.0f) * 0.25f, floor_y);
-
-    // tiles of the clip with something below the floor (n_tiles <= 63: one 64-bit word)
-    if (threadIdx.x < 64) {
-        const bool flag = (int)threadIdx.x < first_pad_tile && key_to_float(~kmin_raw) < floor_lg;
-        const unsigned long long bal = __ballot(flag);
-        if (threadIdx.x == 0) s_flags = bal;
-    }
-    __syncthreads();
-    const unsigned long long flags = s_flags;
-    if (pad_frame >= n_frames && flags == 0ull) return;           // the usual full-length clip: nothing to do
-
-    const int32_t* cm = s_masks;
-    const uint64_t melmask_lo = mask_bits(cm, nm, STTFE_AXIS_FREQ, 0, 64);
-    const uint64_t melmask_hi = mask_bits(cm, nm, STTFE_AXIS_FREQ, 64, 64);
-    int ts[STTFE_MAX_MASKS], te[STTFE_MAX_MASKS], nt = 0;          // time-axis masks of the clip
-    for (int i = 0; i < nm; ++i)
-        if (cm[3 * i] == STTFE_AXIS_TIME && cm[3 * i + 2] > cm[3 * i + 1]) {
-            ts[nt] = cm[3 * i + 1];
-            te[nt] = cm[3 * i + 2];
-            ++nt;
-        }
-    float* __restrict__ o = out + (size_t)clip * n_mels * n_frames;
-    // the workgroup's rows: one block of consecutive mel rows (so that the line a row's padding shares with the start
-    // of the NEXT row belongs to the same workgroup, see the fill)
-    const int rows_per = (n_mels + row_step - 1) / row_step;
-    const int mel_lo = row0 * rows_per;
-    const int rows = max(0, min(rows_per, n_mels - mel_lo));
-
-    // ---- fill.  A row is n_frames floats = 12 000 B long, not a multiple of the 128-byte line, so the padding segment
-    // of every row begins and ends inside a line, and a partly written line costs the memory side a read-modify-write:
-    // with plain segment stores those two lines per row held the whole pass at 4.3 TB/s (tools/ubench/fill_rate.hip:
-    // 5.5 TB/s when they are simply left out).  Lanes are therefore mapped to ABSOLUTE 16-byte slots -- eight lanes per
-    // line -- and the lanes of a first / last line that lie outside the segment read what is there (the row's own last
-    // computed frames; the first frames of the workgroup's next row) and write it back, so that the line goes out
-    // whole: 4.9 TB/s.  Only the last row of a workgroup keeps a partial last line (it belongs to another workgroup).
-    if (pad_frame < n_frames && rows > 0) {
-        const int vq = (((n_frames - pad_frame) * 4 + 127) / 128 + 1) * 8;      // 16-byte slots per row, whole lines
-        const int n_slots = rows * vq;
-        int r = threadIdx.x / vq, v = threadIdx.x - r * vq;
-        const int dr = blockDim.x / vq, dv = blockDim.x - dr * vq;
-        const uintptr_t clip_base = reinterpret_cast<uintptr_t>(o);
-        for (int item = threadIdx.x; item < n_slots; item += blockDim.x) {
-            const int mel = mel_lo + r;
-            const uintptr_t start = clip_base + ((size_t)mel * n_frames + pad_frame) * 4;
-            const uintptr_t end = clip_base + ((size_t)mel * n_frames + n_frames) * 4;
-            const uintptr_t a = (start & ~(uintptr_t)127) + 16u * (uintptr_t)v;
-            if (a >= start && a < end) {
-                const bool mmasked = ((mel < 64 ? melmask_lo >> mel : melmask_hi >> (mel - 64)) & 1ull);
-                const float c = mmasked ? 0.0f : pad_y;
-                *reinterpret_cast<f32x4*>(a) = f32x4{c, c, c, c};
-            } else if ((a < start && a >= clip_base + (size_t)mel * n_frames * 4) ||
-                       (a >= end && a < ((end + 127) & ~(uintptr_t)127) && r + 1 < rows &&
-                        a < end + (size_t)pad_frame * 4)) {
-                // (the tail of a row's last line is kept only where it holds COMPUTED frames of this workgroup's next
-                // row: with short clips or short rows -- pad_frame * 4 < 128 bytes, compact n_frames < 32 -- the line
-                // reaches that row's own fill segment, which its fill lane writes, or rows of another workgroup)
-                const f32x4 keep = *reinterpret_cast<const f32x4*>(a);          // computed cells of this workgroup's rows
-                *reinterpret_cast<f32x4*>(a) = keep;
-            }
-            r += dr;
-            v += dv;
-            if (v >= vq) {
-                v -= vq;
-                ++r;
-            }
-        }
-        if (nt != 0) {                                             // then the few time-masked columns are zeroed
-            __syncthreads();
-            for (int i = 0; i < nt; ++i) {
-                const int a = max(ts[i], pad_frame), w = min(te[i], n_frames) - a;
-                if (w <= 0) continue;
-                for (int e = threadIdx.x; e < rows * w; e += blockDim.x) {
-                    const int r = e / w, c = e - r * w;
-                    o[(size_t)(mel_lo + r) * n_frames + a + c] = 0.0f;
-                }
-            }
-        }
-    }
-    if (flags == 0ull) return;
-
-    // ---- clamp: (flagged tile, row, 4-frame quad) items are dealt round-robin to the threads; a thread loads up to
-    // kBatch items before its first store (the compiler cannot move a load above a store to the same array, and
-    // one HBM round trip per item would make the pass latency-bound).
-    unsigned char* s_tiles = lds.tiles;
-    const int n_flagged = __popcll(flags);
-    if (threadIdx.x < 64 && ((flags >> threadIdx.x) & 1ull))
-        s_tiles[__popcll(flags & ((1ull << threadIdx.x) - 1ull))] = (unsigned char)threadIdx.x;
-    __syncthreads();
-    constexpr int kBatch = 4;
-    constexpr int kQuadsPerTile = kTileFrames / 4;                 // 12
-    const int per_tile = rows * kQuadsPerTile, n_items = n_flagged * per_tile;
-    for (int base = threadIdx.x; base < n_items; base += kBatch * blockDim.x) {
-        int fr0[kBatch], melv[kBatch];
-        f32x4 v[kBatch];
-#pragma unroll
-        for (int i = 0; i < kBatch; ++i) {
-            const int item = base + i * blockDim.x;
-            fr0[i] = -1;
-            if (item < n_items) {
-                const int ti = item / per_tile, rem = item - ti * per_tile;
-                const int r = rem / kQuadsPerTile, qt = rem - r * kQuadsPerTile;
-                const int fr = s_tiles[ti] * kTileFrames + 4 * qt;
-                melv[i] = mel_lo + r;
-                if (fr < pad_frame) {                              // pad_frame is a multiple of 4
-                    fr0[i] = fr;
-                    v[i] = *reinterpret_cast<const f32x4*>(o + (size_t)melv[i] * n_frames + fr);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < kBatch; ++i) {
-            if (fr0[i] < 0) continue;
-            const int mel = melv[i];
-            const bool mmasked = ((mel < 64 ? melmask_lo >> mel : melmask_hi >> (mel - 64)) & 1ull);
-            f32x4 w;
-            bool changed = false;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int fr = fr0[i] + c;
-                float y = fr < key_frames ? fmaxf(v[i][c], floor_y) : v[i][c];   // padding_value cells stay as they are
-                bool masked = mmasked;                             // masked cells of a computed tile already hold 0.0
-                for (int m = 0; m < nt; ++m) masked |= (fr >= ts[m] && fr < te[m]);
-                if (masked) y = 0.0f;
-                changed |= (y != v[i][c]);
-                w[c] = y;
-            }
-            if (changed) *reinterpret_cast<f32x4*>(o + (size_t)mel * n_frames + fr0[i]) = w;
-        }
-    }
-}
-
-// Out of line for kernel 1: inlined, the body's registers come on top of everything the tile loop keeps across items
-// (the prefetched samples, the twiddles) and the kernel spilled 200 registers.
-__device__ __noinline__ void whisper_clamp_fill_call(
-    float* __restrict__ out, const int32_t* __restrict__ lengths, const unsigned* __restrict__ keys,
-    int n_mels, int n_frames, const int32_t* __restrict__ mask_tbl, int n_masks,
-    const float* __restrict__ clip_scale, int mode, float pad_value, int clip, int row0, int row_step,
-    ClampFillLds* lds) {
-    whisper_clamp_fill_rows<true>(out, lengths, keys, n_mels, n_frames, mask_tbl, n_masks, clip_scale, mode, pad_value, clip,
-                                  row0, row_step, *lds);
+    f.pad_y = mode == wh::kModeTorchVarlen ? pad_value : fmaxf((-10.0f + 4.0f) * 0.25f, f.floor_y);
+    return f;
 }
 
 #ifndef STTFE_FLOOR
@@ -467,7 +286,6 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     int fuse) {
     using namespace wh;
     __shared__ __attribute__((aligned(16))) float smem[kLdsFloats];
-    __shared__ ClampFillLds fill_lds;
 
     // a tables blob built for another extractor (wrong magic / n_mels): nothing is computed, kernel 2 poisons the output
     if (tab->magic != kWhisperMagic || tab->n_mels != n_mels) return;
@@ -632,19 +450,22 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         __syncthreads();
         n_items = plan[batch];
     }
-    // Fused clamp / fill (ragged batches whose item space is the clip-major plan above).  Kernel 2's work -- the padding
-    // fill of a short clip is as many bytes as kernel 1 itself moves for it -- becomes kFuseSplit items per clip in the SAME
-    // item space, fill_lag clips behind the clip's own tile runs: block c of the sequence is [runs of clip c][fill items of
-    // clip c - fill_lag].  A workgroup that writes a padding region (memory-bound, no arithmetic) shares its CU with one
-    // that transforms (issue-bound): the two kernels ran one after the other before.  A fill item needs the clip's final
-    // maximum, i.e. every tile run of the clip finished: done[clip] counts them (see the publication at the end of an item);
-    // the lag -- about 1.25 x the resident workgroups' worth of items -- makes the wait the exception.
+    // Fused padding fill (ragged batches whose item space is the clip-major plan above).  The padding region of a short
+    // clip is as many bytes as kernel 1 itself moves for it, and kernel 2 wrote it after kernel 1 had finished.  Its whole
+    // 128-byte lines become kFuseSplit items per clip in the SAME item space, fill_lag clips behind the clip's own tile
+    // runs: block c of the sequence is [runs of clip c][fill items of clip c - fill_lag].  A workgroup that fills
+    // (memory-bound, no arithmetic) then shares its CU with one that transforms (issue-bound).  The constant needs the
+    // clip's final maximum, i.e. every tile run of the clip finished: done[clip] counts them (see the end of an item);
+    // the lag -- about 3.5 x the resident workgroups' worth of items -- makes waiting the exception.  Kernel 2 keeps
+    // the partial first / last line of every row, the time masks and the clamp.
     int fill_lag = 0;
     unsigned* done = ticket + 16;                    // per-clip counters of finished tile runs (zeroed by the host)
 #if !STTFE_FLOOR && !defined(STTFE_STAMPS)
     if (planned && fuse) {
         const int total = n_items + kFuseSplit * batch;
-        fill_lag = min(batch, (int)(((long long)(5 * (int)gridDim.x / 4) * batch + total - 1) / total));
+        // (a workgroup holds three items at a time: the one it works on, the next, whose first samples it has
+        // requested, and the ticket after that)
+        fill_lag = min(batch, (int)(((long long)(7 * (int)gridDim.x / 2) * batch + total - 1) / total));
         if (batch + fill_lag > kMaxPlanClips) fill_lag = 0;
     }
     const bool fused = __builtin_amdgcn_readfirstlane(fill_lag > 0 ? 1 : 0);
@@ -658,7 +479,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         }
         if (tid == kThreads - 1) plan[batch] = runs_total + kFuseSplit * (batch - fill_lag);
         for (int c = batch + 1 + tid; c <= batch + fill_lag; c += kThreads) plan[c] = runs_total + kFuseSplit * (c - fill_lag);
-        if (tid == 0) ticket[1] = 1u;                // kernel 2 of this launch returns at once
+        if (tid == 0) ticket[1] = 1u;                // tells kernel 2 of this launch that the whole lines are written
         __syncthreads();
         n_items = runs_total + kFuseSplit * batch;
     }
@@ -931,22 +752,59 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
       // frames from here on are the padding constant (kernel 2 fills them): not part of a tile's minimum
       const int const_frame = whisper_const_frame(n_valid, n_frames, min(n_frames, min(n_tiles, first_pad_tile_of(n_valid)) * kTileFrames), mode);
       if (run < 0) {
-          // fused clamp / fill item: block -1 - run of the clip's mel rows, once every tile run of the clip has been
-          // published.  Only runs taken before this item can be missing, and a workgroup that holds a run never waits
-          // for anything, so the wait ends; the poll limit is a last resort against a launch whose first workgroups
-          // were never started (half a second; the rows would then be clamped against an unfinished maximum).
-          const int need = runs_of(n_valid);
+          // (the prefetched samples and the twiddles are not needed across a fill item: dead / re-read at its end, so
+          // that the registers of the fill do not come on top of them)
+#pragma unroll
+          for (int m = 0; m < 28; ++m) raw0[m] = raw1[m] = 0.0f;
+          // Fused fill item: the whole 128-byte lines of the padding region of block -1 - run of the clip's mel rows, once
+          // every tile run of the clip has been counted.  Only runs taken before this item can be missing, and a
+          // workgroup that holds a run never waits for anything, so the wait ends; the poll limit is a last resort
+          // against a launch whose first workgroups were never started (half a second; the lines would then hold the
+          // constant of an unfinished maximum).
           if (tid == 0) {
+              const int need = runs_of(n_valid);
               int polls = 0;
               while ((int)__hip_atomic_load(done + clip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && polls < kFillSpinLimit) {
                   __builtin_amdgcn_s_sleep(32);
                   ++polls;
               }
+              if (polls) atomicAdd(ticket + 2, (unsigned)polls);      // diagnostic: total polls of the launch (workspace word)
           }
           __syncthreads();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // the other workgroups' features and keys, not stale lines
-          whisper_clamp_fill_call(out, lengths, keys, n_mels, n_frames, mask_tbl, n_masks, clip_scale, mode, pad_value,
-                                  clip, -1 - run, kFuseSplit, &fill_lds);
+          const int rows_per = (n_mels + kFuseSplit - 1) / kFuseSplit, mel_lo = (-1 - run) * rows_per;
+          const int rows = max(0, min(rows_per, n_mels - mel_lo));
+          if (const_frame < n_frames && rows > 0) {
+              const unsigned kmax = __hip_atomic_load(keys + (size_t)clip * kKeysPerClip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const float pad_y = whisper_floor(kmax, clip_scale, clip, mode, pad_value).pad_y;
+              const int32_t* cm = mask_tbl + (size_t)clip * n_masks * 3;       // (mel-masked rows are 0.0; time masks: kernel 2)
+              const int nmk = mask_tbl ? n_masks : 0;
+              const uint64_t mm_lo = mask_bits(cm, nmk, STTFE_AXIS_FREQ, 0, 64), mm_hi = mask_bits(cm, nmk, STTFE_AXIS_FREQ, 64, 64);
+              const uintptr_t clip_base = reinterpret_cast<uintptr_t>(out + (size_t)clip * n_mels * n_frames);
+              const int vq = (((n_frames - const_frame) * 4) / 128 + 1) * 8;      // 16-byte slots per row (upper bound of the whole lines)
+              const int n_slots = rows * vq;
+              int r = tid / vq, v = tid - r * vq;
+              const int dr = kThreads / vq, dv = kThreads - dr * vq;
+              for (int i = tid; i < n_slots; i += kThreads) {
+                  const int mel = mel_lo + r;
+                  const uintptr_t start = clip_base + ((size_t)mel * n_frames + const_frame) * 4;
+                  const uintptr_t end = clip_base + ((size_t)mel * n_frames + n_frames) * 4;
+                  const uintptr_t a = ((start + 127) & ~(uintptr_t)127) + 16u * (uintptr_t)v;
+                  if (a + 16 <= (end & ~(uintptr_t)127)) {
+                      const bool mmasked = ((mel < 64 ? mm_lo >> mel : mm_hi >> (mel - 64)) & 1ull);
+                      const float c = mmasked ? 0.0f : pad_y;
+                      *reinterpret_cast<f32x4*>(a) = f32x4{c, c, c, c};
+                  }
+                  r += dr;
+                  v += dv;
+                  if (v >= vq) {
+                      v -= vq;
+                      ++r;
+                  }
+                  for (int k = 1; k < fuse; ++k) __builtin_amdgcn_s_sleep(1);     // EXPERIMENT: throttle
+              }
+          }
+#pragma unroll
+          for (int q = 0; q < 10; ++q) t4[q] = tw4[q];
       } else if (tile_begin < tile_end) {
       float* __restrict__ out_clip = out + (size_t)clip * n_mels * n_frames;
       // SpecAugment: mel-axis masks as two 64-bit words for the clip; time-axis masks per tile
@@ -1065,7 +923,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 #define STTFE_U(NM, MT, FT) \
     mel_unit_static<NM, MT, STTFE_MASKED>(a_lane, b##FT, ob + MT * nf16 + FT * 16, o_r, mel_floor, y_bias, run_max, tile_min, \
                                           (unsigned)(tmask >> (FT * 16)) & 0xffffu,                                     \
-                                          (unsigned)((MT < 4 ? melmask_lo : melmask_hi) >> ((MT & 3) * 16)) & 0xffffu, lane, fused)
+                                          (unsigned)((MT < 4 ? melmask_lo : melmask_hi) >> ((MT & 3) * 16)) & 0xffffu, lane)
             if (nm == 0) {
 #define STTFE_MASKED false
             if (static_plan == 80) {
@@ -1128,11 +986,6 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 #if STTFE_FLOOR == 8
         const int nu = 0;                                           // floor build: no mel projection at all
 #endif
-        // (fused fill: write-through stores, as in the static units)
-        auto put = [fused](float* p, float v) {
-            if (fused) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else *p = v;
-        };
         int4v d = desc[0];                                          // {kstart, nsteps, aoff, mt | ft << 8}
         int ks = __builtin_amdgcn_readfirstlane(d.x), ns = __builtin_amdgcn_readfirstlane(d.y);
         int ao = __builtin_amdgcn_readfirstlane(d.z), code = __builtin_amdgcn_readfirstlane(d.w);
@@ -1190,12 +1043,15 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
                 for (int r = 0; r < 4; ++r) {
                     run_max = fmaxf(run_max, mv[r]);
                     tile_min = fminf(tile_min, mv[r]);
-                    put(out_clip + (o0 + (unsigned)(r * n_frames)), yv[r]);
+                    out_clip[o0 + (unsigned)(r * n_frames)] = yv[r];
                 }
             } else {
                 const bool tmasked = (tmask >> fl) & 1ull;
                 const unsigned mbits = (unsigned)((mel0 < 64 ? melmask_lo >> mel0 : melmask_hi >> (mel0 - 64)) & 15ull);
-                const bool counted = t0 + fl < key_frames, stored = t0 + fl < n_frames, varies = t0 + fl < const_frame;
+                // (fused fill: the cells from const_frame on belong to the fill -- a fill item on another XCD and this
+                // store would leave the same bytes dirty in two L2s, and whichever is written back last would win)
+                const bool counted = t0 + fl < key_frames, varies = t0 + fl < const_frame;
+                const bool stored = t0 + fl < n_frames && (varies || !fused);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (mel0 + r < n_mels) {
@@ -1204,8 +1060,8 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
                             if (varies) tile_min = fminf(tile_min, mv[r]);
                         }
                         if (stored)
-                            put(out_clip + (o0 + (unsigned)(r * n_frames)),
-                                (tmasked || ((mbits >> r) & 1u)) ? 0.0f : (counted ? yv[r] : pad_value));
+                            out_clip[o0 + (unsigned)(r * n_frames)] =
+                                (tmasked || ((mbits >> r) & 1u)) ? 0.0f : (counted ? yv[r] : pad_value);
                     }
                 }
             }
@@ -1231,7 +1087,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
       // the barrier of the following item, which every thread reaches after this read)
       unsigned* slot = reinterpret_cast<unsigned*>(smem + kTicketOff) + 1 + (iter & 1u);
       if (tid == 0) *slot = (next_item < n_items) ? my_ticket + 2 * gridDim.x : (unsigned)n_items;
-      // fused fill: this run's features (write-through stores) and key atomics are complete before the clip's counter moves
+      // fused fill: this run's key atomics have landed before the clip's counter moves
       if (fused && run >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (fused && run >= 0 && tid == 0) __hip_atomic_fetch_add(done + clip, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1265,6 +1121,12 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 #endif
 }
 
+// Clamp / fill pass.  grid.x = row split, grid.y = clips: workgroup x owns mel rows x, x + gridDim.x, ... of its clip.
+//   fill : the clip's zero-padding region [first padding frame, n_frames) gets the final constant with full-row
+//          vector stores (kernel 1 never touches it);
+//   clamp: of the computed tiles only those whose recorded minimum is below max - 8 (a few per cent of the tiles of
+//          ordinary audio; none for most clips) are re-read and clamped to (max - 8 + 4) / 4.
+// SpecAugment masks -> 0.0 on everything written.
 __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     float* __restrict__ out, const int32_t* __restrict__ lengths, const unsigned* __restrict__ keys,
     int n_mels, int n_frames, const int32_t* __restrict__ mask_tbl, int n_masks,
@@ -1273,6 +1135,7 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     using namespace wh;
     const int clip = blockIdx.y;
     const int row0 = blockIdx.x, row_step = gridDim.x;
+    const bool lines_done = *fused_flag != 0u;      // kernel 1 has written the whole lines of every padding region (ragged batch)
     if (tab->magic != kWhisperMagic || tab->n_mels != n_mels) {
         // STTFE_E_TABLES cannot be returned without synchronising: the whole output becomes NaN instead (loud, and
         // never uninitialised memory)
@@ -1281,10 +1144,160 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
                 out[((size_t)clip * n_mels + mel) * n_frames + t] = __builtin_nanf("");
         return;
     }
-    if (*fused_flag != 0u) return;        // kernel 1 has done this launch's clamp / fill work itself (ragged batch)
-    __shared__ ClampFillLds lds;
-    whisper_clamp_fill_rows<false>(out, lengths, keys, n_mels, n_frames, mask_tbl, n_masks, clip_scale, mode, pad_value, clip,
-                                   row0, row_step, lds);
+    // Everything the workgroup needs from memory is requested in ONE batch (length, max key, the per-tile min keys,
+    // the clip's mask table -> LDS): with four dependent round trips per workgroup this kernel was latency-bound
+    // (0.10 ms for 32 k workgroups that find nothing to clamp).
+    __shared__ unsigned long long s_flags;
+    __shared__ int32_t s_masks[3 * STTFE_MAX_MASKS];
+    const int nm = mask_tbl ? n_masks : 0;
+    int n_valid = lengths[clip];
+    const unsigned kmax = keys[(size_t)clip * kKeysPerClip];
+    unsigned kmin_raw = 0xffffffffu;
+    if (threadIdx.x < kKeysPerClip - 1) kmin_raw = keys[(size_t)clip * kKeysPerClip + 1 + threadIdx.x];
+    if ((int)threadIdx.x < 3 * nm) s_masks[threadIdx.x] = mask_tbl[(size_t)clip * n_masks * 3 + threadIdx.x];
+    const int len_cap = mode == kModeTorchVarlen ? kVarMaxSamples : kMaxSamples;
+    n_valid = n_valid < 0 ? 0 : (n_valid > len_cap ? len_cap : n_valid);
+    const int n_tiles = (n_frames + kTileFrames - 1) / kTileFrames;
+    const int first_pad_tile = min(n_tiles, mode == kModeTorchVarlen
+                                                ? (1 + n_valid / kHop + kTileFrames - 1) / kTileFrames
+                                                : (n_valid + kNfft / 2 + kHop * kTileFrames - 1) / (kHop * kTileFrames));
+    // first frame of the constant region (a multiple of 4)
+    const int pad_frame = whisper_const_frame(n_valid, n_frames, min(n_frames, first_pad_tile * kTileFrames), mode);
+    const int key_frames = mode == kModeTorchVarlen ? 1 + n_valid / kHop : n_frames;   // frames that hold data
+    const WhisperFloor fl = whisper_floor(kmax, clip_scale, clip, mode, pad_value);
+    const float floor_lg = fl.floor_lg, floor_y = fl.floor_y, pad_y = fl.pad_y;
+
+    // tiles of the clip with something below the floor (n_tiles <= 63: one 64-bit word)
+    if (threadIdx.x < 64) {
+        const bool flag = (int)threadIdx.x < first_pad_tile && key_to_float(~kmin_raw) < floor_lg;
+        const unsigned long long bal = __ballot(flag);
+        if (threadIdx.x == 0) s_flags = bal;
+    }
+    __syncthreads();
+    const unsigned long long flags = s_flags;
+    if (pad_frame >= n_frames && flags == 0ull) return;           // the usual full-length clip: nothing to do
+
+    const int32_t* cm = s_masks;
+    const uint64_t melmask_lo = mask_bits(cm, nm, STTFE_AXIS_FREQ, 0, 64);
+    const uint64_t melmask_hi = mask_bits(cm, nm, STTFE_AXIS_FREQ, 64, 64);
+    int ts[STTFE_MAX_MASKS], te[STTFE_MAX_MASKS], nt = 0;          // time-axis masks of the clip
+    for (int i = 0; i < nm; ++i)
+        if (cm[3 * i] == STTFE_AXIS_TIME && cm[3 * i + 2] > cm[3 * i + 1]) {
+            ts[nt] = cm[3 * i + 1];
+            te[nt] = cm[3 * i + 2];
+            ++nt;
+        }
+    float* __restrict__ o = out + (size_t)clip * n_mels * n_frames;
+    // the workgroup's rows: one block of consecutive mel rows (so that the line a row's padding shares with the start
+    // of the NEXT row belongs to the same workgroup, see the fill)
+    const int rows_per = (n_mels + row_step - 1) / row_step;
+    const int mel_lo = row0 * rows_per;
+    const int rows = max(0, min(rows_per, n_mels - mel_lo));
+
+    // ---- fill.  A row is n_frames floats = 12 000 B long, not a multiple of the 128-byte line, so the padding segment
+    // of every row begins and ends inside a line, and a partly written line costs the memory side a read-modify-write:
+    // with plain segment stores those two lines per row held the whole pass at 4.3 TB/s (tools/ubench/fill_rate.hip:
+    // 5.5 TB/s when they are simply left out).  Lanes are therefore mapped to ABSOLUTE 16-byte slots -- eight lanes per
+    // line -- and the lanes of a first / last line that lie outside the segment read what is there (the row's own last
+    // computed frames; the first frames of the workgroup's next row) and write it back, so that the line goes out
+    // whole: 4.9 TB/s.  Only the last row of a workgroup keeps a partial last line (it belongs to another workgroup).
+    if (pad_frame < n_frames && rows > 0) {
+        const int vq = (((n_frames - pad_frame) * 4 + 127) / 128 + 1) * 8;      // 16-byte slots per row, whole lines
+        const int n_slots = rows * vq;
+        int r = threadIdx.x / vq, v = threadIdx.x - r * vq;
+        const int dr = blockDim.x / vq, dv = blockDim.x - dr * vq;
+        const uintptr_t clip_base = reinterpret_cast<uintptr_t>(o);
+        for (int item = threadIdx.x; item < n_slots; item += blockDim.x) {
+            const int mel = mel_lo + r;
+            const uintptr_t start = clip_base + ((size_t)mel * n_frames + pad_frame) * 4;
+            const uintptr_t end = clip_base + ((size_t)mel * n_frames + n_frames) * 4;
+            const uintptr_t a = (start & ~(uintptr_t)127) + 16u * (uintptr_t)v;
+            const uintptr_t line = a & ~(uintptr_t)127;
+            if (lines_done && line >= start && line + 128 <= end) {
+                // (a whole line inside the region: kernel 1's fill item wrote it)
+            } else if (a >= start && a < end) {
+                const bool mmasked = ((mel < 64 ? melmask_lo >> mel : melmask_hi >> (mel - 64)) & 1ull);
+                const float c = mmasked ? 0.0f : pad_y;
+                *reinterpret_cast<f32x4*>(a) = f32x4{c, c, c, c};
+            } else if ((a < start && a >= clip_base + (size_t)mel * n_frames * 4) ||
+                       (a >= end && a < ((end + 127) & ~(uintptr_t)127) && r + 1 < rows &&
+                        a < end + (size_t)pad_frame * 4)) {
+                // (the tail of a row's last line is kept only where it holds COMPUTED frames of this workgroup's next
+                // row: with short clips or short rows -- pad_frame * 4 < 128 bytes, compact n_frames < 32 -- the line
+                // reaches that row's own fill segment, which its fill lane writes, or rows of another workgroup)
+                const f32x4 keep = *reinterpret_cast<const f32x4*>(a);          // computed cells of this workgroup's rows
+                *reinterpret_cast<f32x4*>(a) = keep;
+            }
+            r += dr;
+            v += dv;
+            if (v >= vq) {
+                v -= vq;
+                ++r;
+            }
+        }
+        if (nt != 0) {                                             // then the few time-masked columns are zeroed
+            __syncthreads();
+            for (int i = 0; i < nt; ++i) {
+                const int a = max(ts[i], pad_frame), w = min(te[i], n_frames) - a;
+                if (w <= 0) continue;
+                for (int e = threadIdx.x; e < rows * w; e += blockDim.x) {
+                    const int r = e / w, c = e - r * w;
+                    o[(size_t)(mel_lo + r) * n_frames + a + c] = 0.0f;
+                }
+            }
+        }
+    }
+    if (flags == 0ull) return;
+
+    // ---- clamp: (flagged tile, row, 4-frame quad) items are dealt round-robin to the threads; a thread loads up to
+    // kBatch items before its first store (the compiler cannot move a load above a store to the same array, and
+    // one HBM round trip per item would make the pass latency-bound).
+    __shared__ unsigned char s_tiles[64];
+    const int n_flagged = __popcll(flags);
+    if (threadIdx.x < 64 && ((flags >> threadIdx.x) & 1ull))
+        s_tiles[__popcll(flags & ((1ull << threadIdx.x) - 1ull))] = (unsigned char)threadIdx.x;
+    __syncthreads();
+    constexpr int kBatch = 4;
+    constexpr int kQuadsPerTile = kTileFrames / 4;                 // 12
+    const int per_tile = rows * kQuadsPerTile, n_items = n_flagged * per_tile;
+    for (int base = threadIdx.x; base < n_items; base += kBatch * blockDim.x) {
+        int fr0[kBatch], melv[kBatch];
+        f32x4 v[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+            const int item = base + i * blockDim.x;
+            fr0[i] = -1;
+            if (item < n_items) {
+                const int ti = item / per_tile, rem = item - ti * per_tile;
+                const int r = rem / kQuadsPerTile, qt = rem - r * kQuadsPerTile;
+                const int fr = s_tiles[ti] * kTileFrames + 4 * qt;
+                melv[i] = mel_lo + r;
+                if (fr < pad_frame) {                              // pad_frame is a multiple of 4
+                    fr0[i] = fr;
+                    v[i] = *reinterpret_cast<const f32x4*>(o + (size_t)melv[i] * n_frames + fr);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+            if (fr0[i] < 0) continue;
+            const int mel = melv[i];
+            const bool mmasked = ((mel < 64 ? melmask_lo >> mel : melmask_hi >> (mel - 64)) & 1ull);
+            f32x4 w;
+            bool changed = false;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int fr = fr0[i] + c;
+                float y = fr < key_frames ? fmaxf(v[i][c], floor_y) : v[i][c];   // padding_value cells stay as they are
+                bool masked = mmasked;                             // masked cells of a computed tile already hold 0.0
+                for (int m = 0; m < nt; ++m) masked |= (fr >= ts[m] && fr < te[m]);
+                if (masked) y = 0.0f;
+                changed |= (y != v[i][c]);
+                w[c] = y;
+            }
+            if (changed) *reinterpret_cast<f32x4*>(o + (size_t)mel * n_frames + fr0[i]) = w;
+        }
+    }
 }
 
 }  // namespace sttfe
@@ -1300,7 +1313,7 @@ extern "C" int sttfe_debug_set_stamp_buffer(void* dev_buf) {
 
 extern "C" int sttfe_whisper_workspace_bytes(int batch, size_t* bytes) {
     if (batch < 0 || !bytes) return STTFE_E_INVALID_ARG;
-    // keys + the work-item ticket counter (64 B) + per clip the finished tile runs (fused clamp / fill)
+    // keys + the work-item ticket counter (64 B) + per clip the finished tile runs (fused padding fill)
     *bytes = (size_t)batch * wh::kKeysPerClip * sizeof(unsigned) + 64 + (((size_t)batch * sizeof(unsigned) + 63) & ~(size_t)63);
     return STTFE_OK;
 }
@@ -1361,8 +1374,8 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
     // tiles_per_block == 0: the kernel picks the run length itself from the clip lengths it finds on the device
     if ((long)n_tiles * batch > 0x3fffffffL) return STTFE_E_UNSUPPORTED;
     static const int fuse_env = [] {
-        const char* e = getenv("STTFE_WH_FUSE_FILL");             // 0: clamp / fill always as kernel 2 (A/B, diagnosis)
-        return e ? (atoi(e) != 0) : 1;
+        const char* e = getenv("STTFE_WH_FUSE_FILL");             // 0: the padding fill always in kernel 2 (A/B, diagnosis)
+        return e ? atoi(e) : 1;
     }();
     const int resident = 2 * current_device_cus();
     const long most_items = (long)batch * ((n_tiles + 2) / 3);      // fewer workgroups than that cannot all find work
