@@ -86,8 +86,6 @@ constexpr int kMaskOff = kTicketOff + 4;              // the current clip's Spec
 constexpr int kPlanOff = kMaskOff + 3 * STTFE_MAX_MASKS;      // ragged batches: exclusive prefix of the clips' run counts
 constexpr int kMaxPlanClips = 3072;                   // (12 KB; larger batches keep the dense run x clip item space)
 constexpr int kLdsFloats = kPlanOff + kMaxPlanClips + 1;   // ~77 KB -> 2 workgroups per CU
-constexpr int kFuseSplit = 4;                         // fused padding fill: items (blocks of mel rows) per clip
-constexpr int kFillSpinLimit = 1 << 19;               // polls (~1 us each) a fill item waits for its clip before it goes ahead anyway
 }  // namespace wh
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -253,24 +251,6 @@ __device__ __forceinline__ int whisper_const_frame(int n_valid, int n_frames, in
     return min(min(f, tile_pad_frame), n_frames);
 }
 
-// The constant of a clip's padding region (kernel 2, and the fused fill items of kernel 1), from the clip's max key.
-// Scaled clips (see kernel 1): keys are log10 of the unscaled energies, stored values carry the bias c / 4 with
-// c = 2 log10(s); the zero padding is log10(1e-10) = -10 in the scaled domain, i.e. -10 - c in the keys' domain.
-struct WhisperFloor {
-    float floor_lg, floor_y, pad_y;
-};
-__device__ __forceinline__ WhisperFloor whisper_floor(unsigned kmax, const float* __restrict__ clip_scale, int clip, int mode,
-                                                      float pad_value) {
-    const float c_lg = clip_scale ? 2.0f * 0.30102999566398120f * __log2f(clip_scale[clip]) : 0.0f;
-    const float lmax = kmax ? key_to_float(kmax) : -10.0f - c_lg; // no computed tile at all: the floor itself
-    WhisperFloor f;
-    f.floor_lg = lmax - 8.0f;
-    f.floor_y = (f.floor_lg + 4.0f) * 0.25f + 0.25f * c_lg;
-    // zero padding to 30 s: log10(1e-10) clamped like everything else; variable-length mode: the literal padding_value
-    f.pad_y = mode == wh::kModeTorchVarlen ? pad_value : fmaxf((-10.0f + 4.0f) * 0.25f, f.floor_y);
-    return f;
-}
-
 #ifndef STTFE_FLOOR
 #define STTFE_FLOOR 0
 #endif
@@ -282,8 +262,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     const int32_t* __restrict__ lengths, int n_mels, int n_frames,
     const WhisperTablesHeader* __restrict__ tab, float* __restrict__ out,
     unsigned* __restrict__ keys, const int32_t* __restrict__ mask_tbl, int n_masks, int tiles_per_block,
-    int batch, unsigned* __restrict__ ticket, const float* __restrict__ clip_scale, int mode, float pad_value,
-    int fuse) {
+    int batch, unsigned* __restrict__ ticket, const float* __restrict__ clip_scale, int mode, float pad_value) {
     using namespace wh;
     __shared__ __attribute__((aligned(16))) float smem[kLdsFloats];
 
@@ -450,69 +429,21 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         __syncthreads();
         n_items = plan[batch];
     }
-    // Fused padding fill (ragged batches whose item space is the clip-major plan above).  The padding region of a short
-    // clip is as many bytes as kernel 1 itself moves for it, and kernel 2 wrote it after kernel 1 had finished.  Its whole
-    // 128-byte lines become kFuseSplit items per clip in the SAME item space, fill_lag clips behind the clip's own tile
-    // runs: block c of the sequence is [runs of clip c][fill items of clip c - fill_lag].  A workgroup that fills
-    // (memory-bound, no arithmetic) then shares its CU with one that transforms (issue-bound).  The constant needs the
-    // clip's final maximum, i.e. every tile run of the clip finished: done[clip] counts them (see the end of an item);
-    // the lag -- about 3.5 x the resident workgroups' worth of items -- makes waiting the exception.  Kernel 2 keeps
-    // the partial first / last line of every row, the time masks and the clamp.
-    int fill_lag = 0;
-    unsigned* done = ticket + 16;                    // per-clip counters of finished tile runs (zeroed by the host)
-#if !STTFE_FLOOR && !defined(STTFE_STAMPS)
-    if (planned && fuse) {
-        const int total = n_items + kFuseSplit * batch;
-        // (a workgroup holds three items at a time: the one it works on, the next, whose first samples it has
-        // requested, and the ticket after that)
-        fill_lag = min(batch, (int)(((long long)(7 * (int)gridDim.x / 2) * batch + total - 1) / total));
-        if (batch + fill_lag > kMaxPlanClips) fill_lag = 0;
-    }
-    const bool fused = __builtin_amdgcn_readfirstlane(fill_lag > 0 ? 1 : 0);
-    if (fused) {
-        // plan[c] += kFuseSplit * max(0, c - lag) for c <= batch, then the lag blocks that hold only fill items
-        const int runs_total = n_items;
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const int c = tid * per + k;
-            if (k < per && c < batch) plan[c] += kFuseSplit * max(0, c - fill_lag);
-        }
-        if (tid == kThreads - 1) plan[batch] = runs_total + kFuseSplit * (batch - fill_lag);
-        for (int c = batch + 1 + tid; c <= batch + fill_lag; c += kThreads) plan[c] = runs_total + kFuseSplit * (c - fill_lag);
-        if (tid == 0) ticket[1] = 1u;                // tells kernel 2 of this launch that the whole lines are written
-        __syncthreads();
-        n_items = runs_total + kFuseSplit * batch;
-    }
-#else
-    const bool fused = false;
-#endif
-    const int n_blocks = batch + fill_lag;           // blocks of the item sequence (== clips without the fused fill)
-    // item -> (clip, run); with the fused fill: run < 0 = fill item -1 - run of the clip
+    // item -> (clip, run)
     auto decode = [&](int it, int& clip_out, int& run_out) {
         if (planned) {
             // largest c with plan[c] <= it (plan is strictly increasing: every clip has a run), two 64-way steps: the
             // lanes sample plan at 64 points / read one block of it, and a ballot counts the entries <= it
             // (a bisection's 12 dependent LDS reads were 1.7 k cycles per item)
-            const int stride = (n_blocks + 63) >> 6;
+            const int stride = (batch + 63) >> 6;
             const int c1 = lane * stride;
-            const bool le1 = c1 < n_blocks && plan[min(c1, n_blocks)] <= it;
+            const bool le1 = c1 < batch && plan[min(c1, batch)] <= it;
             const int block = __popcll(__ballot(le1)) - 1;                  // >= 0: plan[0] = 0 <= it
             const int c2 = block * stride + lane;
-            const bool le2 = lane < stride && c2 < n_blocks && plan[min(c2, n_blocks)] <= it;
-            int c = block * stride + __popcll(__ballot(le2)) - 1;
-            c = __builtin_amdgcn_readfirstlane(c);
-            int off = __builtin_amdgcn_readfirstlane(it - plan[c]);
-            if (fused) {
-                // block c: the tile runs of clip c (if c < batch), then the fill items of clip c - fill_lag (if c >= fill_lag);
-                // a fill item comes back as run = -1 - (block of mel rows)
-                const int runs_c = c < batch ? __builtin_amdgcn_readfirstlane(plan[c + 1] - plan[c]) - (c >= fill_lag ? kFuseSplit : 0) : 0;
-                if (off >= runs_c) {
-                    off = -1 - (off - runs_c);
-                    c -= fill_lag;
-                }
-            }
-            clip_out = c;
-            run_out = off;
+            const bool le2 = lane < stride && c2 < batch && plan[min(c2, batch)] <= it;
+            const int c = block * stride + __popcll(__ballot(le2)) - 1;
+            clip_out = __builtin_amdgcn_readfirstlane(c);
+            run_out = __builtin_amdgcn_readfirstlane(it - plan[c]);
         } else {
             run_out = __builtin_amdgcn_readfirstlane(it / batch);
             clip_out = __builtin_amdgcn_readfirstlane(it - run_out * batch);
@@ -751,61 +682,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
       const int key_frames = mode == kModeTorchVarlen ? 1 + n_valid / kHop : (mode == kModeTorchPadded ? n_frames + 1 : n_frames);
       // frames from here on are the padding constant (kernel 2 fills them): not part of a tile's minimum
       const int const_frame = whisper_const_frame(n_valid, n_frames, min(n_frames, min(n_tiles, first_pad_tile_of(n_valid)) * kTileFrames), mode);
-      if (run < 0) {
-          // (the prefetched samples and the twiddles are not needed across a fill item: dead / re-read at its end, so
-          // that the registers of the fill do not come on top of them)
-#pragma unroll
-          for (int m = 0; m < 28; ++m) raw0[m] = raw1[m] = 0.0f;
-          // Fused fill item: the whole 128-byte lines of the padding region of block -1 - run of the clip's mel rows, once
-          // every tile run of the clip has been counted.  Only runs taken before this item can be missing, and a
-          // workgroup that holds a run never waits for anything, so the wait ends; the poll limit is a last resort
-          // against a launch whose first workgroups were never started (half a second; the lines would then hold the
-          // constant of an unfinished maximum).
-          if (tid == 0) {
-              const int need = runs_of(n_valid);
-              int polls = 0;
-              while ((int)__hip_atomic_load(done + clip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && polls < kFillSpinLimit) {
-                  __builtin_amdgcn_s_sleep(32);
-                  ++polls;
-              }
-              if (polls) atomicAdd(ticket + 2, (unsigned)polls);      // diagnostic: total polls of the launch (workspace word)
-          }
-          __syncthreads();
-          const int rows_per = (n_mels + kFuseSplit - 1) / kFuseSplit, mel_lo = (-1 - run) * rows_per;
-          const int rows = max(0, min(rows_per, n_mels - mel_lo));
-          if (const_frame < n_frames && rows > 0) {
-              const unsigned kmax = __hip_atomic_load(keys + (size_t)clip * kKeysPerClip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              const float pad_y = whisper_floor(kmax, clip_scale, clip, mode, pad_value).pad_y;
-              const int32_t* cm = mask_tbl + (size_t)clip * n_masks * 3;       // (mel-masked rows are 0.0; time masks: kernel 2)
-              const int nmk = mask_tbl ? n_masks : 0;
-              const uint64_t mm_lo = mask_bits(cm, nmk, STTFE_AXIS_FREQ, 0, 64), mm_hi = mask_bits(cm, nmk, STTFE_AXIS_FREQ, 64, 64);
-              const uintptr_t clip_base = reinterpret_cast<uintptr_t>(out + (size_t)clip * n_mels * n_frames);
-              const int vq = (((n_frames - const_frame) * 4) / 128 + 1) * 8;      // 16-byte slots per row (upper bound of the whole lines)
-              const int n_slots = rows * vq;
-              int r = tid / vq, v = tid - r * vq;
-              const int dr = kThreads / vq, dv = kThreads - dr * vq;
-              for (int i = tid; i < n_slots; i += kThreads) {
-                  const int mel = mel_lo + r;
-                  const uintptr_t start = clip_base + ((size_t)mel * n_frames + const_frame) * 4;
-                  const uintptr_t end = clip_base + ((size_t)mel * n_frames + n_frames) * 4;
-                  const uintptr_t a = ((start + 127) & ~(uintptr_t)127) + 16u * (uintptr_t)v;
-                  if (a + 16 <= (end & ~(uintptr_t)127)) {
-                      const bool mmasked = ((mel < 64 ? mm_lo >> mel : mm_hi >> (mel - 64)) & 1ull);
-                      const float c = mmasked ? 0.0f : pad_y;
-                      *reinterpret_cast<f32x4*>(a) = f32x4{c, c, c, c};
-                  }
-                  r += dr;
-                  v += dv;
-                  if (v >= vq) {
-                      v -= vq;
-                      ++r;
-                  }
-                  for (int k = 1; k < fuse; ++k) __builtin_amdgcn_s_sleep(1);     // EXPERIMENT: throttle
-              }
-          }
-#pragma unroll
-          for (int q = 0; q < 10; ++q) t4[q] = tw4[q];
-      } else if (tile_begin < tile_end) {
+      if (tile_begin < tile_end) {
       float* __restrict__ out_clip = out + (size_t)clip * n_mels * n_frames;
       // SpecAugment: mel-axis masks as two 64-bit words for the clip; time-axis masks per tile
       // The clip's mask table goes to LDS once per item (read per tile from global memory it cost one HBM round
@@ -870,7 +747,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         if (tile + 1 < tile_end) {
             load_pass(x, n_valid, t0 + kTileFrames, 0, raw0);
             load_pass(x, n_valid, t0 + kTileFrames, 1, raw1);
-        } else if (next_item < n_items && run_nx >= 0) {
+        } else if (next_item < n_items) {
             // (the empty asm makes these values opaque here: otherwise the compiler computes the 56 load indices and
             // bounds predicates of the next item at the top of this item and spills them across the whole tile loop)
             int nv = clamp_len(__builtin_amdgcn_readfirstlane(len_next)), tb = __builtin_amdgcn_readfirstlane(run_nx * tiles_per_block);
@@ -1048,10 +925,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
             } else {
                 const bool tmasked = (tmask >> fl) & 1ull;
                 const unsigned mbits = (unsigned)((mel0 < 64 ? melmask_lo >> mel0 : melmask_hi >> (mel0 - 64)) & 15ull);
-                // (fused fill: the cells from const_frame on belong to the fill -- a fill item on another XCD and this
-                // store would leave the same bytes dirty in two L2s, and whichever is written back last would win)
-                const bool counted = t0 + fl < key_frames, varies = t0 + fl < const_frame;
-                const bool stored = t0 + fl < n_frames && (varies || !fused);
+                const bool counted = t0 + fl < key_frames, stored = t0 + fl < n_frames, varies = t0 + fl < const_frame;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (mel0 + r < n_mels) {
@@ -1087,10 +961,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
       // the barrier of the following item, which every thread reaches after this read)
       unsigned* slot = reinterpret_cast<unsigned*>(smem + kTicketOff) + 1 + (iter & 1u);
       if (tid == 0) *slot = (next_item < n_items) ? my_ticket + 2 * gridDim.x : (unsigned)n_items;
-      // fused fill: this run's key atomics have landed before the clip's counter moves
-      if (fused && run >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (fused && run >= 0 && tid == 0) __hip_atomic_fetch_add(done + clip, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int after_next = (int)min(*slot, (unsigned)n_items);
 #ifdef STTFE_STAMPS
       STAMP(16);      // diagnostic: end of the item's last tile -> ticket hand-over barrier passed
@@ -1130,12 +1001,10 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
 __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     float* __restrict__ out, const int32_t* __restrict__ lengths, const unsigned* __restrict__ keys,
     int n_mels, int n_frames, const int32_t* __restrict__ mask_tbl, int n_masks,
-    const float* __restrict__ clip_scale, int mode, float pad_value, const WhisperTablesHeader* __restrict__ tab,
-    const unsigned* __restrict__ fused_flag) {
+    const float* __restrict__ clip_scale, int mode, float pad_value, const WhisperTablesHeader* __restrict__ tab) {
     using namespace wh;
     const int clip = blockIdx.y;
     const int row0 = blockIdx.x, row_step = gridDim.x;
-    const bool lines_done = *fused_flag != 0u;      // kernel 1 has written the whole lines of every padding region (ragged batch)
     if (tab->magic != kWhisperMagic || tab->n_mels != n_mels) {
         // STTFE_E_TABLES cannot be returned without synchronising: the whole output becomes NaN instead (loud, and
         // never uninitialised memory)
@@ -1164,8 +1033,14 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     // first frame of the constant region (a multiple of 4)
     const int pad_frame = whisper_const_frame(n_valid, n_frames, min(n_frames, first_pad_tile * kTileFrames), mode);
     const int key_frames = mode == kModeTorchVarlen ? 1 + n_valid / kHop : n_frames;   // frames that hold data
-    const WhisperFloor fl = whisper_floor(kmax, clip_scale, clip, mode, pad_value);
-    const float floor_lg = fl.floor_lg, floor_y = fl.floor_y, pad_y = fl.pad_y;
+    // scaled clips (see kernel 1): keys are log10 of the unscaled energies, stored values carry the bias c / 4 with
+    // c = 2 log10(s); the zero padding is log10(1e-10) = -10 in the scaled domain, i.e. -10 - c in the keys' domain
+    const float c_lg = clip_scale ? 2.0f * 0.30102999566398120f * __log2f(clip_scale[clip]) : 0.0f;
+    const float lmax = kmax ? key_to_float(kmax) : -10.0f - c_lg; // no computed tile at all: the floor itself
+    const float floor_lg = lmax - 8.0f;
+    const float floor_y = (floor_lg + 4.0f) * 0.25f + 0.25f * c_lg;
+    // zero padding to 30 s: log10(1e-10) clamped like everything else; variable-length mode: the literal padding_value
+    const float pad_y = mode == kModeTorchVarlen ? pad_value : fmaxf((-10.0f + 4.0f) * 0.25f, floor_y);
 
     // tiles of the clip with something below the floor (n_tiles <= 63: one 64-bit word)
     if (threadIdx.x < 64) {
@@ -1212,10 +1087,7 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
             const uintptr_t start = clip_base + ((size_t)mel * n_frames + pad_frame) * 4;
             const uintptr_t end = clip_base + ((size_t)mel * n_frames + n_frames) * 4;
             const uintptr_t a = (start & ~(uintptr_t)127) + 16u * (uintptr_t)v;
-            const uintptr_t line = a & ~(uintptr_t)127;
-            if (lines_done && line >= start && line + 128 <= end) {
-                // (a whole line inside the region: kernel 1's fill item wrote it)
-            } else if (a >= start && a < end) {
+            if (a >= start && a < end) {
                 const bool mmasked = ((mel < 64 ? melmask_lo >> mel : melmask_hi >> (mel - 64)) & 1ull);
                 const float c = mmasked ? 0.0f : pad_y;
                 *reinterpret_cast<f32x4*>(a) = f32x4{c, c, c, c};
@@ -1313,8 +1185,7 @@ extern "C" int sttfe_debug_set_stamp_buffer(void* dev_buf) {
 
 extern "C" int sttfe_whisper_workspace_bytes(int batch, size_t* bytes) {
     if (batch < 0 || !bytes) return STTFE_E_INVALID_ARG;
-    // keys + the work-item ticket counter (64 B) + per clip the finished tile runs (fused padding fill)
-    *bytes = (size_t)batch * wh::kKeysPerClip * sizeof(unsigned) + 64 + (((size_t)batch * sizeof(unsigned) + 63) & ~(size_t)63);
+    *bytes = (size_t)batch * wh::kKeysPerClip * sizeof(unsigned) + 64;      // keys + the work-item ticket counter
     return STTFE_OK;
 }
 
@@ -1373,10 +1244,6 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
     // workgroups balanced when clip lengths differ, and the tables are staged once per workgroup, not per run.
     // tiles_per_block == 0: the kernel picks the run length itself from the clip lengths it finds on the device
     if ((long)n_tiles * batch > 0x3fffffffL) return STTFE_E_UNSUPPORTED;
-    static const int fuse_env = [] {
-        const char* e = getenv("STTFE_WH_FUSE_FILL");             // 0: the padding fill always in kernel 2 (A/B, diagnosis)
-        return e ? atoi(e) : 1;
-    }();
     const int resident = 2 * current_device_cus();
     const long most_items = (long)batch * ((n_tiles + 2) / 3);      // fewer workgroups than that cannot all find work
     const int grid = most_items < resident ? (int)most_items : resident;
@@ -1391,7 +1258,7 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
 #endif
         hipLaunchKernelGGL(whisper_stft_mel_kernel, dim3(grid), dim3(wh::kThreads), dyn_lds, stream,
                            pcm, offsets, lengths, n_mels, n_frames, tab, out, keys, mask_tbl, n_masks, tiles_per_block,
-                           batch, keys + (size_t)batch * wh::kKeysPerClip, clip_scale, mode, pad_value, fuse_env);
+                           batch, keys + (size_t)batch * wh::kKeysPerClip, clip_scale, mode, pad_value);
     }
     {
         ScopedTiming t(kTimeWhisperClamp, stream);
@@ -1403,8 +1270,7 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
         }();
         const int row_split = row_split_env ? row_split_env : (n_mels > 96 ? (n_mels + 3) / 4 : (n_mels + 4) / 5);
         hipLaunchKernelGGL(whisper_clamp_fill_kernel, dim3(row_split, batch), dim3(256), 0, stream, out, lengths, keys,
-                           n_mels, n_frames, mask_tbl, n_masks, clip_scale, mode, pad_value, tab,
-                           keys + (size_t)batch * wh::kKeysPerClip + 1);
+                           n_mels, n_frames, mask_tbl, n_masks, clip_scale, mode, pad_value, tab);
     }
     if (hip_failed(hipGetLastError(), "whisper kernel launch")) return STTFE_E_LAUNCH;
     return STTFE_OK;
@@ -1437,7 +1303,7 @@ extern "C" int sttfe_whisper_logmel_torch(const float* pcm, const int64_t* offse
 namespace sttfe {
 namespace wh {
 constexpr int kStaticMaxBatch = STTFE_WHISPER_STATIC_MAX_BATCH;
-constexpr size_t kStaticWords = (size_t)kStaticMaxBatch * (kKeysPerClip + 1) + 16;   // keys + the ticket counter (64 B) + run counters
+constexpr size_t kStaticWords = (size_t)kStaticMaxBatch * kKeysPerClip + 16;     // keys + the ticket counter (64 B)
 constexpr int kMaxDevices = 64;
 }  // namespace wh
 static __device__ __align__(256) unsigned scratch[wh::kStaticWords];
