@@ -38,7 +38,7 @@ for d in sorted(glob.glob(prefix + "*")):
     flags = " --fused-normalize" if wl.endswith("_fused") else ""
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_pmc.py"), d, pmc,
                     f"bash tools/profile_round.sh <tag> {wl.replace('_fused', '')}{flags}  (one rocprofv3 run per pass over `python3 "
-                    f"bench.py --workload {wl.replace('_fused', '')} --steps 4 --warmup 2 --settle-seconds 0 --no-cpu-baseline{flags}`)"],
+                    f"bench.py --workload {wl.replace('_fused', '')} --steps 4 --warmup 2 --settle-seconds 0 --no-cpu-baseline --no-e2e{flags}`)"],
                    check=True, stdout=subprocess.DEVNULL)
     counters = json.load(open(pmc))["counters"]
     per_kernel = {}

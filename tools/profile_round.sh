@@ -7,7 +7,7 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 export TMPDIR=/tmp
 out=gpurun_out/$tag
 mkdir -p $out
-CMD="bench.py --workload $wl --steps 4 --warmup 2 --settle-seconds 0 --no-cpu-baseline $*"
+CMD="bench.py --workload $wl --steps 4 --warmup 2 --settle-seconds 0 --no-cpu-baseline --no-e2e $*"
 run() {
     name=$1; shift
     timeout -s KILL 150 rocprofv3 "$@" --output-format csv -d $out/$name -- python3 $CMD > $out/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $out/$name.log; exit 1; }
