@@ -201,7 +201,11 @@ __device__ __forceinline__ void mel_unit_static(const float* __restrict__ a_lane
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
+#if STTFE_FLOOR == 9 || STTFE_FLOOR == 11
+        const f32x4 av = {mel_floor, y_bias, mel_floor, y_bias}, bv = {y_bias, mel_floor, y_bias, mel_floor};   // floor build: no operand reads
+#else
         const f32x4 av = a[g * 64], bv = b[4 * g];
+#endif
 #if STTFE_FLOOR == 4 || STTFE_FLOOR == 6
         acc += av * bv;                                               // floor build: operand reads without the MFMAs
 #else
@@ -216,11 +220,15 @@ __device__ __forceinline__ void mel_unit_static(const float* __restrict__ a_lane
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         mv[r] = fmaxf(acc[r], mel_floor);
+#if STTFE_FLOOR == 10 || STTFE_FLOOR == 11
+        yv[r] = mv[r];                                                // floor build: no logarithm
+#else
         yv[r] = fmaf(__log2f(mv[r]), 0.25f * 0.30102999566398120f, y_bias);
+#endif
     }
 #pragma unroll                                                        // opaque in place: the zero-extension then stays beside
     for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(o_r[r]));      // the store, which takes scalar base + 32-bit lane offset
-#if STTFE_FLOOR == 7
+#if STTFE_FLOOR == 7 || STTFE_FLOOR == 11
     run_max = fmaxf(run_max, (yv[0] + yv[1]) + (yv[2] + yv[3]));      // floor build: no feature stores
     return;
 #endif
@@ -235,8 +243,10 @@ __device__ __forceinline__ void mel_unit_static(const float* __restrict__ a_lane
         for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(reinterpret_cast<char*>(out_u) + o_r[r]) = yv[r];
     }
     // max / min count the masked cells too: the masks are applied to the finished features (src/data.py:185-194)
+#if STTFE_FLOOR != 10
     run_max = fmaxf(fmaxf(run_max, fmaxf(mv[0], mv[1])), fmaxf(mv[2], mv[3]));
     tile_min = fminf(fminf(tile_min, fminf(mv[0], mv[1])), fminf(mv[2], mv[3]));
+#endif
 }
 
 // First frame (a multiple of 4) from which every cell of a clip is the padding constant.  Zero padding to 30 s: frame t
@@ -499,6 +509,7 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     //   4: the whole kernel with the mel projection's MFMAs replaced by one packed multiply-add per operand pair
     //   5: the whole kernel without the two workgroup barriers of the tile loop;  6: both 4 and 5
     //   7: the whole kernel without the feature stores;  8: without the mel phase (operand reads, MFMAs, epilogue, stores)
+    //   9: the mel units' operands from registers instead of LDS;  10: no logarithm, no min / max keys;  11: 7 + 9 + no logarithm
     f2 floor_sink = {0.0f, 0.0f};
 #pragma unroll
     for (int m = 0; m < 28; ++m) {
