@@ -61,6 +61,36 @@ def test_matches_oracle_on_seeded_batch(n_mels, fe80, fe128):
     assert float(err.max()) <= TOL, err
 
 
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_clamp_in_scattered_units_matches_the_oracle(n_mels, fe80, fe128):
+    """Cells below max - 8 in some mel bands of some 16-frame groups only: kernel 2 re-reads just the units of the waves
+    of kernel 1 that flagged them (per-tile, per-wave minimum keys), so a wrong unit -> wave map would leave cells unclamped."""
+    from oracle.whisper import whisper_features
+    fe = fe80 if n_mels == 80 else fe128
+    rng = np.random.default_rng(77)
+    clips = []
+    for n in (480000, 300000, 123456):
+        t = np.arange(n) / 16000.0
+        x = np.zeros(n, dtype=np.float64)
+        # a loud tone sets the clip's maximum; short band-limited bursts of very different levels come and go, so that
+        # which bands and which frames fall below the floor changes from unit to unit
+        x += 0.8 * np.sin(2 * np.pi * 440.0 * t) * (t < 0.5)
+        for k in range(int(t[-1] * 8)):
+            f0 = rng.uniform(100.0, 7800.0)
+            lvl = 10.0 ** rng.uniform(-6.5, -1.0)
+            s0 = int(rng.uniform(0, n - 2000))
+            seg = slice(s0, s0 + int(rng.uniform(800, 6000)))
+            x[seg] += lvl * np.sin(2 * np.pi * f0 * t[seg])
+        x += 1e-7 * rng.standard_normal(n)
+        clips.append(x.astype(np.float32))
+    got = fe(clips, sampling_rate=16000).input_features.cpu().numpy()
+    exp = whisper_features(clips, n_mels)
+    floor_cells = (exp == exp.reshape(len(clips), -1).min(axis=1)[:, None, None]).mean()
+    assert 0.02 < floor_cells < 0.98, floor_cells                  # the clamp is at work, and not everywhere
+    err = np.abs(got - exp).reshape(len(clips), -1).max(axis=1)
+    assert float(err.max()) <= TOL, err
+
+
 def test_input_forms_and_errors(fe80):
     clip = synth_clip(np.random.default_rng(5), 8000, zero_block=False)
     ref = fe80(clip, sampling_rate=16000).input_features
