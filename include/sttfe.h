@@ -122,7 +122,7 @@ int sttfe_whisper_logmel_torch(const float* pcm, const int64_t* offsets, const i
  * graph capture, tight serving loops and harnesses that forbid hipMalloc, which cannot size and provide the
  * `workspace` argument above.  Same inputs, outputs and results as sttfe_whisper_logmel; the workspace (per-clip max
  * key, per-tile min keys, work-item ticket counter) is a device array inside the library:
- * 4 * (256 * STTFE_WHISPER_STATIC_MAX_BATCH + 16) bytes (4 MiB + 64 B) on every GPU the library runs on, held until the
+ * 4 * (64 * STTFE_WHISPER_STATIC_MAX_BATCH + 16) bytes (1 MiB + 64 B) on every GPU the library runs on, held until the
  * process ends.  batch > STTFE_WHISPER_STATIC_MAX_BATCH returns STTFE_E_UNSUPPORTED (sttfe_last_error_detail() says
  * why).  The call allocates and frees nothing (the array's device address is looked up once per device, on the first
  * call made with that device current: hipGetSymbolAddress, which may load the code object and is not legal under

@@ -66,7 +66,7 @@ constexpr int kModeTorchPadded = 1; // pad / truncate to 30 s, per-clip max over
 constexpr int kModeTorchVarlen = 2; // no padding: reflect at the clip's own end, 1 + n / 160 frames, max over them,
                                     // crop to 3000, frames past the clip's own <- padding_value (:222-239)
 constexpr int kMaxTiles = 63;                 // ceil(3000 / 48)
-constexpr int kKeysPerClip = 256;             // workspace: [0] = max key, [1 + 4 t + w] = ~min key of what wave w computed of tile t
+constexpr int kKeysPerClip = 64;              // workspace: [0] = max key, [1 + t] = ~min key of tile t
 constexpr int kRowStride = 22;                // complex units, [k1][n2] rows: 176 B, so a row reads as 10 x b128
 constexpr int kPairStride = 20 * kRowStride;  // complex units per frame pair (880 floats == 48 mod 64 banks)
 constexpr int kPStride = 204;                 // floats per frame row of the power panel: 16-byte rows, 12 n mod 64 banks -> conflict-free b128 operand reads
@@ -955,10 +955,8 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
         }   // generic unit loop
         // per-tile minimum (kernel 2 re-reads only the tiles that hold something below max - 8)
         tile_min = wave_min(tile_min);
-        // (one word per tile and wave: a single writer, a plain store; kernel 2 re-reads only the units of the waves
-        // whose minimum lies below the floor -- with one key per tile it re-read whole tiles, four times the cells)
         if (lane == 0 && tile_min < 1.0e38f && tile < kMaxTiles)       // (tiles behind the output have no min key: not stored)
-            keys[(size_t)clip * kKeysPerClip + 1 + 4 * tile + wave] = (~float_to_key(__log2f(tile_min) * 0.30102999566398120f));
+            atomicMax(&keys[(size_t)clip * kKeysPerClip + 1 + tile], ~float_to_key(__log2f(tile_min) * 0.30102999566398120f));
         STAMP(7);
 #if STTFE_FLOOR != 5 && STTFE_FLOOR != 6
         __syncthreads();      // panel reads done before the next tile's slab writes
@@ -1030,22 +1028,13 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     // the clip's mask table -> LDS): with four dependent round trips per workgroup this kernel was latency-bound
     // (0.10 ms for 32 k workgroups that find nothing to clamp).
     __shared__ unsigned long long s_flags;
-    __shared__ unsigned long long s_wflags[4];                    // 4 bits per tile: which waves of kernel 1 left a cell below the floor
-    __shared__ unsigned char s_owner[kMaxMelTiles * kFrameTiles]; // (mel tile, frame tile) unit -> the wave of kernel 1 that computes it
     __shared__ int32_t s_masks[3 * STTFE_MAX_MASKS];
     const int nm = mask_tbl ? n_masks : 0;
     int n_valid = lengths[clip];
     const unsigned kmax = keys[(size_t)clip * kKeysPerClip];
-    unsigned kmin_raw = 0xffffffffu;                              // thread 4 t + w: tile t, wave w
-    if (threadIdx.x < 4 * kMaxTiles) kmin_raw = keys[(size_t)clip * kKeysPerClip + 1 + threadIdx.x];
+    unsigned kmin_raw = 0xffffffffu;
+    if (threadIdx.x < kKeysPerClip - 1) kmin_raw = keys[(size_t)clip * kKeysPerClip + 1 + threadIdx.x];
     if ((int)threadIdx.x < 3 * nm) s_masks[threadIdx.x] = mask_tbl[(size_t)clip * n_masks * 3 + threadIdx.x];
-    if (threadIdx.x < kWaves * kMaxUnitsPerWave) {                // the unit plan kernel 1 follows (tables.cpp; the static
-        const int w = threadIdx.x / kMaxUnitsPerWave, u = threadIdx.x - w * kMaxUnitsPerWave;      // lists are the same)
-        if (u < tab->plan.wave_nunits[w]) {
-            const int code = tab->plan.wave_units[w][u];
-            s_owner[(code & 0xff) * kFrameTiles + (code >> 8)] = (unsigned char)w;
-        }
-    }
     const int len_cap = mode == kModeTorchVarlen ? kVarMaxSamples : kMaxSamples;
     n_valid = n_valid < 0 ? 0 : (n_valid > len_cap ? len_cap : n_valid);
     const int n_tiles = (n_frames + kTileFrames - 1) / kTileFrames;
@@ -1064,16 +1053,9 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     // zero padding to 30 s: log10(1e-10) clamped like everything else; variable-length mode: the literal padding_value
     const float pad_y = mode == kModeTorchVarlen ? pad_value : fmaxf((-10.0f + 4.0f) * 0.25f, floor_y);
 
-    // (tile, wave) pairs of the clip with something below the floor: 4 bits per tile, 16 tiles per wave of this kernel
-    {
-        const bool flag = (int)(threadIdx.x >> 2) < first_pad_tile && key_to_float(~kmin_raw) < floor_lg;
-        const unsigned long long bal = __ballot(flag);
-        if ((threadIdx.x & 63) == 0) s_wflags[threadIdx.x >> 6] = bal;
-    }
-    __syncthreads();
-    // tiles with any such wave (n_tiles <= 63: one 64-bit word)
+    // tiles of the clip with something below the floor (n_tiles <= 63: one 64-bit word)
     if (threadIdx.x < 64) {
-        const bool flag = ((s_wflags[threadIdx.x >> 4] >> ((threadIdx.x & 15) * 4)) & 15ull) != 0ull;
+        const bool flag = (int)threadIdx.x < first_pad_tile && key_to_float(~kmin_raw) < floor_lg;
         const unsigned long long bal = __ballot(flag);
         if (threadIdx.x == 0) s_flags = bal;
     }
@@ -1171,13 +1153,9 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
             if (item < n_items) {
                 const int ti = item / per_tile, rem = item - ti * per_tile;
                 const int r = rem / kQuadsPerTile, qt = rem - r * kQuadsPerTile;
-                const int tl = s_tiles[ti];
-                const int fr = tl * kTileFrames + 4 * qt;
+                const int fr = s_tiles[ti] * kTileFrames + 4 * qt;
                 melv[i] = mel_lo + r;
-                // only the units of the waves that flagged the tile (a unit = 16 mel rows x 16 frames)
-                const unsigned wv = (unsigned)(s_wflags[tl >> 4] >> ((tl & 15) * 4)) & 15u;
-                const bool unit_flagged = (wv >> s_owner[(melv[i] >> 4) * kFrameTiles + (qt >> 2)]) & 1u;
-                if (fr < pad_frame && unit_flagged) {              // pad_frame is a multiple of 4
+                if (fr < pad_frame) {                              // pad_frame is a multiple of 4
                     fr0[i] = fr;
                     v[i] = *reinterpret_cast<const f32x4*>(o + (size_t)melv[i] * n_frames + fr);
                 }
@@ -1336,7 +1314,7 @@ extern "C" int sttfe_whisper_logmel_torch(const float* pcm, const int64_t* offse
 namespace sttfe {
 namespace wh {
 constexpr int kStaticMaxBatch = STTFE_WHISPER_STATIC_MAX_BATCH;
-constexpr size_t kStaticWords = (size_t)kStaticMaxBatch * kKeysPerClip + 16;     // keys (1 KiB per clip) + the ticket counter (64 B)
+constexpr size_t kStaticWords = (size_t)kStaticMaxBatch * kKeysPerClip + 16;     // keys + the ticket counter (64 B)
 constexpr int kMaxDevices = 64;
 }  // namespace wh
 static __device__ __align__(256) unsigned scratch[wh::kStaticWords];
