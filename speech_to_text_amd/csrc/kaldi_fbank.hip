@@ -730,7 +730,7 @@ __global__ __launch_bounds__(kaldi64::kThreads, kaldi64::kWgPerCu) void kaldi_fb
             asm volatile("" : "+v"(lane_o));                          // loads inside the loop instead of 60 registers
 #pragma unroll
             for (int q = 1; q < 8; ++q) {
-                const int i1 = (lane_o * q) & 511;
+                const int i1 = (int)__umul24((unsigned)lane_o, (unsigned)q) & 511;      // (24-bit multiply: full rate)
                 const double2k w = *reinterpret_cast<const double2k*>(w512 + 2 * i1);
                 tw1[q] = cd{w.x, w.y};
             }
