@@ -1183,6 +1183,9 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     }
 }
 
+#ifdef STTFE_WH12
+#include "whisper_logmel12.inc"
+#endif
 }  // namespace sttfe
 
 using namespace sttfe;
@@ -1259,6 +1262,23 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
     const long most_items = (long)batch * ((n_tiles + 2) / 3);      // fewer workgroups than that cannot all find work
     const int grid = most_items < resident ? (int)most_items : resident;
     const auto* tab = reinterpret_cast<const WhisperTablesHeader*>(dev_tables);
+#ifdef STTFE_WH12
+    const bool wh12_on = getenv("STTFE_WH12") && atoi(getenv("STTFE_WH12")) != 0;      // read per call: the check script toggles it
+    if (wh12_on && n_mels == 80 && mode == wh::kModeHF && !mask_tbl && !clip_scale) {
+        const int tpr_env = getenv("STTFE_WH12_TILES") ? atoi(getenv("STTFE_WH12_TILES")) : 7;
+        const int n_tiles12 = (n_frames + wh12::kTileFrames - 1) / wh12::kTileFrames;
+        const int tpr = tpr_env < 1 ? 7 : tpr_env, n_runs = (n_tiles12 + tpr - 1) / tpr;
+        const long items = (long)n_runs * batch;
+        const int grid12 = items < current_device_cus() ? (int)items : current_device_cus();
+        const size_t lds = (size_t)wh12::kLdsFloats * sizeof(float);
+        if (hip_failed(hipFuncSetAttribute(reinterpret_cast<const void*>(whisper_stft_mel12_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"))
+            return STTFE_E_LAUNCH;
+        ScopedTiming t(kTimeWhisperStftMel, stream);
+        hipLaunchKernelGGL(whisper_stft_mel12_kernel, dim3(grid12), dim3(wh12::kThreads), lds, stream, pcm, offsets, lengths,
+                           n_frames, tab, out, keys, batch, tpr, n_runs);
+    } else
+#endif
     {
         ScopedTiming t(kTimeWhisperStftMel, stream);
 #ifdef STTFE_STAMPS
