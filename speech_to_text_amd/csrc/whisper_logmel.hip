@@ -1265,11 +1265,10 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
 #ifdef STTFE_WH12
     const bool wh12_on = getenv("STTFE_WH12") && atoi(getenv("STTFE_WH12")) != 0;      // read per call: the check script toggles it
     if (wh12_on && n_mels == 80 && mode == wh::kModeHF && !mask_tbl && !clip_scale) {
-        const int tpr_env = getenv("STTFE_WH12_TILES") ? atoi(getenv("STTFE_WH12_TILES")) : 7;
-        const int n_tiles12 = (n_frames + wh12::kTileFrames - 1) / wh12::kTileFrames;
-        const int tpr = tpr_env < 1 ? 7 : tpr_env, n_runs = (n_tiles12 + tpr - 1) / tpr;
-        const long items = (long)n_runs * batch;
-        const int grid12 = items < current_device_cus() ? (int)items : current_device_cus();
+        const int tpr_env = getenv("STTFE_WH12_TILES") ? atoi(getenv("STTFE_WH12_TILES")) : 21;
+        const int tpr = tpr_env < 1 ? 21 : tpr_env, n_runs = (n_tiles + tpr - 1) / tpr;
+        const long wgs = ((long)n_runs * batch + wh12::kGroups - 1) / wh12::kGroups;     // three item-walking groups per workgroup
+        const int grid12 = wgs < current_device_cus() ? (int)wgs : current_device_cus();
         const size_t lds = (size_t)wh12::kLdsFloats * sizeof(float);
         if (hip_failed(hipFuncSetAttribute(reinterpret_cast<const void*>(whisper_stft_mel12_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"))

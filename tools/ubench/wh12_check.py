@@ -50,9 +50,9 @@ pcm = synth_batch_device(1, B, 480000, dev).reshape(-1)
 off = (torch.arange(B, dtype=torch.int64) * 480000).to(dev)
 ln = torch.full((B,), 480000, dtype=torch.int32, device=dev)
 out = torch.empty((B, 80, 3000), dtype=torch.float32, device=dev)
-for proto, tiles in ((0, 0), (1, 7), (1, 3), (1, 21), (0, 0)):
+for proto, tiles in ((0, 0), (1, 21), (1, 7), (1, 9), (1, 63), (0, 0)):
     os.environ["STTFE_WH12"] = str(proto)
-    os.environ["STTFE_WH12_TILES"] = str(tiles or 7)
+    os.environ["STTFE_WH12_TILES"] = str(tiles or 21)
     L.sttfe_timing_enable(256)
     L.sttfe_timing_set_stride(1 << 30)
     for _ in range(40):
