@@ -281,6 +281,17 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if defined(STTFE_PRIO)
+    // Experiment: unequal wave priorities for the two workgroups of a CU, so that one of them
+    // always wins the VALU and the other's transform falls into its mel phases.  1: by wave slot parity (HW_ID),
+    // 2: second half of the grid, 3: odd workgroups
+    {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        const bool hi = STTFE_PRIO == 1 ? (hw & 1u) : (STTFE_PRIO == 2 ? blockIdx.x >= gridDim.x / 2 : (blockIdx.x & 1u));
+        if (hi) __builtin_amdgcn_s_setprio(3);
+    }
+#endif
 #ifdef STTFE_STAMPS
     unsigned long long stamp_entry;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_entry)::"memory");
@@ -1267,7 +1278,7 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
     if (wh12_on && n_mels == 80 && mode == wh::kModeHF && !mask_tbl && !clip_scale) {
         const int tpr_env = getenv("STTFE_WH12_TILES") ? atoi(getenv("STTFE_WH12_TILES")) : 21;
         const int tpr = tpr_env < 1 ? 21 : tpr_env, n_runs = (n_tiles + tpr - 1) / tpr;
-        const long wgs = ((long)n_runs * batch + wh12::kGroups - 1) / wh12::kGroups;     // three item-walking groups per workgroup
+        const long wgs = (long)n_runs * batch;
         const int grid12 = wgs < current_device_cus() ? (int)wgs : current_device_cus();
         const size_t lds = (size_t)wh12::kLdsFloats * sizeof(float);
         if (hip_failed(hipFuncSetAttribute(reinterpret_cast<const void*>(whisper_stft_mel12_kernel),
