@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Phase times of the specialised-wave prototype (make -C speech_to_text_amd/csrc wh12-stamps):
+STTFE_LIB_PATH=$PWD/tools/ubench/whisper12_stamps.so STTFE_WH12=1 python3 tools/ubench/wh12_stamps.py"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from speech_to_text_amd import _lib
+from speech_to_text_amd.processors import HipWhisperFeatureExtractor
+from speech_to_text_amd.synth import synth_batch_device
+os.environ["STTFE_WH12"] = "1"
+B = 1024
+dev = torch.device("cuda:0")
+L = _lib.lib()
+nblk = 256
+buf = torch.zeros(nblk * 12 * 20, dtype=torch.int64, device=dev)
+L.sttfe_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
+assert L.sttfe_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr())) == 0
+fe = HipWhisperFeatureExtractor(80, device=dev)
+pcm = synth_batch_device(1, B, 480000, dev).reshape(-1)
+off = (torch.arange(B, dtype=torch.int64) * 480000).to(dev)
+ln = torch.full((B,), 480000, dtype=torch.int32, device=dev)
+out = torch.empty((B, 80, 3000), dtype=torch.float32, device=dev)
+for _ in range(3):
+    fe.extract(pcm, off, ln, out=out)
+torch.cuda.synchronize()
+raw = buf.view(nblk, 12, 20).double()
+tiles = B * 63 / nblk
+names = ["transform (s1 .. power)", "wait at B1", "panel rows", "wait at B2", "mel units + keys", "item switches", "tail"]
+for role, sl in (("transform waves 0-7", slice(0, 8)), ("mel waves 8-11", slice(8, 12))):
+    r = raw[:, sl, :]
+    life = (r[:, :, 14] - r[:, :, 13]).mean()
+    print(f"{role}: lifetime {life:.0f} cycles = {life / tiles:.0f} per tile")
+    for i, n in enumerate(names):
+        print(f"   {n:26s} {r[:, :, i].mean() / tiles:8.0f} cycles/tile")
