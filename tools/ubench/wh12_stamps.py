@@ -25,7 +25,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 raw = buf.view(nblk, 12, 20).double()
 tiles = B * 63 / nblk
-names = ["transform (s1 .. power)", "wait at B1", "panel rows", "wait at B2", "mel units + keys", "item switches", "tail"]
+names = ["s1: window, DFT, twiddles, slab", "wait for the panel (freed)", "panel rows + signal", "mel: wait for the panel", "mel units + keys", "loop top", "s2: DFT, partner, power", "tail"]
 for role, sl in (("transform waves 0-7", slice(0, 8)), ("mel waves 8-11", slice(8, 12))):
     r = raw[:, sl, :]
     life = (r[:, :, 14] - r[:, :, 13]).mean()
