@@ -37,6 +37,7 @@ def _declare(lib):
         "sttfe_whisper_logmel_torch": [p, p, p, c_int, c_int, c_int, p, p, p, c_int, c_int, c_float, p, c_size_t, p],
         "sttfe_whisper_logmel_static": [p, p, p, c_int, c_int, c_int, p, p, p, c_int, p],
         "sttfe_set_whisper_tiles_per_block": [c_int],
+        "sttfe_set_whisper_uniform_kernel": [c_int],
         "sttfe_timing_enable": [c_int],
         "sttfe_timing_reset": [],
         "sttfe_timing_set_stride": [c_int],

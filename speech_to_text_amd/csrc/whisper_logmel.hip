@@ -261,6 +261,17 @@ __device__ __forceinline__ int whisper_const_frame(int n_valid, int n_frames, in
     return min(min(f, tile_pad_frame), n_frames);
 }
 
+// HF mode: first 48-frame tile that lies entirely in the zero padding to 30 s (as first_pad_tile_of in the kernels)
+__device__ __forceinline__ int whisper_first_pad_tile_hf(int n_valid) {
+    return (n_valid + wh::kNfft / 2 + wh::kHop * wh::kTileFrames - 1) / (wh::kHop * wh::kTileFrames);
+}
+// A batch is uniform when its shortest clip ends within a tile of its longest one.  Uniform batches take long runs
+// (a third of the clip) -- and, for the calls whisper_stft_mel12_kernel serves, that kernel instead of this file's
+// whisper_stft_mel_kernel: both kernels evaluate this same predicate on the same lengths, so exactly one of them works.
+__device__ __forceinline__ bool whisper_batch_is_uniform(int min_len, int max_tiles) {
+    return whisper_first_pad_tile_hf(min_len) + 1 >= max_tiles;
+}
+
 #ifndef STTFE_FLOOR
 #define STTFE_FLOOR 0
 #endif
@@ -272,7 +283,8 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     const int32_t* __restrict__ lengths, int n_mels, int n_frames,
     const WhisperTablesHeader* __restrict__ tab, float* __restrict__ out,
     unsigned* __restrict__ keys, const int32_t* __restrict__ mask_tbl, int n_masks, int tiles_per_block,
-    int batch, unsigned* __restrict__ ticket, const float* __restrict__ clip_scale, int mode, float pad_value) {
+    int batch, unsigned* __restrict__ ticket, const float* __restrict__ clip_scale, int mode, float pad_value,
+    int skip_uniform) {
     using namespace wh;
     __shared__ __attribute__((aligned(16))) float smem[kLdsFloats];
 
@@ -403,6 +415,8 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     // of the clip for (near-)uniform batches; otherwise about eight items per workgroup (runs of 3 tiles for batches
     // of 512-1024 Common-Voice-length clips: 0.136 ms against 0.149 ms with a fifth of the longest clip, config 3).
     const int max_tiles = min(n_tiles, first_pad_tile_of(max_len));
+    // (HF mode only, set by the host for the calls whisper_stft_mel12_kernel serves: that kernel has computed this batch)
+    if (skip_uniform && whisper_batch_is_uniform(min_len, max_tiles)) return;
     if (tiles_per_block <= 0) {
         const bool uniform = first_pad_tile_of(min_len) + 1 >= max_tiles;
         tiles_per_block = uniform ? (max_tiles + 2) / 3
@@ -1194,9 +1208,7 @@ __global__ __launch_bounds__(256) void whisper_clamp_fill_kernel(
     }
 }
 
-#ifdef STTFE_WH12
 #include "whisper_logmel12.inc"
-#endif
 }  // namespace sttfe
 
 using namespace sttfe;
@@ -1238,6 +1250,45 @@ int current_device_cus() {
 }
 }  // namespace sttfe
 
+// The 12-wave kernel for uniform batches (whisper_logmel12.inc): on by default; sttfe_set_whisper_uniform_kernel(0) or
+// STTFE_WH_UNIFORM_KERNEL=0 sends every call to whisper_stft_mel_kernel (A/B runs, parity tests).  The diagnostic builds
+// (phase stamps, floor builds) measure whisper_stft_mel_kernel and start with it off.
+static std::atomic<int> g_whisper_uniform_kernel{-1};       // -1: not set through the API
+extern "C" int sttfe_set_whisper_uniform_kernel(int on) {
+    if (on != 0 && on != 1) return STTFE_E_INVALID_ARG;
+    g_whisper_uniform_kernel.store(on, std::memory_order_relaxed);
+    return STTFE_OK;
+}
+static bool whisper_uniform_kernel_enabled() {
+    const int api = g_whisper_uniform_kernel.load(std::memory_order_relaxed);
+    if (api >= 0) return api != 0;
+    static const int env = [] {
+        const char* e = getenv("STTFE_WH_UNIFORM_KERNEL");
+#if defined(STTFE_STAMPS) || STTFE_FLOOR
+        return e ? (atoi(e) != 0) : 0;
+#else
+        return e ? (atoi(e) != 0) : 1;
+#endif
+    }();
+    return env != 0;
+}
+// The kernel needs 147 KB of dynamic LDS: raised once per device (0 = not tried, 1 = ready, 2 = refused -> never used).
+static bool whisper_uniform_kernel_ready() {
+    static std::atomic<int> state[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    int st = state[dev].load(std::memory_order_acquire);
+    if (st == 0) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(whisper_stft_mel12_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)(wh12::kLdsFloats * sizeof(float)));
+        if (e != hipSuccess) (void)hipGetLastError();
+        st = e == hipSuccess ? 1 : 2;
+        state[dev].store(st, std::memory_order_release);
+    }
+    return st == 1;
+}
+
 static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const int32_t* lengths,
                                int batch, int n_mels, int n_frames, const void* dev_tables,
                                float* out, const int32_t* mask_tbl, int n_masks, const float* clip_scale,
@@ -1273,24 +1324,21 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
     const long most_items = (long)batch * ((n_tiles + 2) / 3);      // fewer workgroups than that cannot all find work
     const int grid = most_items < resident ? (int)most_items : resident;
     const auto* tab = reinterpret_cast<const WhisperTablesHeader*>(dev_tables);
-#ifdef STTFE_WH12
-    const bool wh12_on = getenv("STTFE_WH12") && atoi(getenv("STTFE_WH12")) != 0;      // read per call: the check script toggles it
-    if (wh12_on && n_mels == 80 && mode == wh::kModeHF && !mask_tbl && !clip_scale) {
-        const int tpr_env = getenv("STTFE_WH12_TILES") ? atoi(getenv("STTFE_WH12_TILES")) : 21;
-        const int tpr = tpr_env < 1 ? 21 : tpr_env, n_runs = (n_tiles + tpr - 1) / tpr;
-        const long wgs = (long)n_runs * batch;
-        const int grid12 = wgs < current_device_cus() ? (int)wgs : current_device_cus();
-        const size_t lds = (size_t)wh12::kLdsFloats * sizeof(float);
-        if (hip_failed(hipFuncSetAttribute(reinterpret_cast<const void*>(whisper_stft_mel12_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"))
-            return STTFE_E_LAUNCH;
-        ScopedTiming t(kTimeWhisperStftMel, stream);
-        hipLaunchKernelGGL(whisper_stft_mel12_kernel, dim3(grid12), dim3(wh12::kThreads), lds, stream, pcm, offsets, lengths,
-                           n_frames, tab, out, keys, batch, tpr, n_runs);
-    } else
-#endif
+    // Uniform batches of the 80-bin extractor (HF mode, no masks, no per-clip scale) are computed by
+    // whisper_stft_mel12_kernel (whisper_logmel12.inc).  Whether a batch is uniform is only known on the device, so such a
+    // call launches BOTH kernels and each returns at once if the batch is the other's (the same predicate on the same
+    // lengths: whisper_batch_is_uniform); a ragged batch pays one empty launch (~3 us) for it.
+    const bool try_uniform = whisper_uniform_kernel_enabled() && n_mels == 80 && mode == wh::kModeHF &&
+                             (!mask_tbl || n_masks == 0) && !clip_scale && batch <= 16384 && whisper_uniform_kernel_ready();
     {
         ScopedTiming t(kTimeWhisperStftMel, stream);
+        if (try_uniform) {
+            const int cus = current_device_cus();
+            const int grid12 = most_items < cus ? (int)most_items : cus;
+            hipLaunchKernelGGL(whisper_stft_mel12_kernel, dim3(grid12), dim3(wh12::kThreads),
+                               (size_t)wh12::kLdsFloats * sizeof(float), stream, pcm, offsets, lengths, n_frames, tab, out, keys,
+                               batch, tiles_per_block, 1);
+        }
 #ifdef STTFE_STAMPS
         // diagnostic build: extra dynamic LDS forces one workgroup per CU (phase times without a co-resident workgroup)
         static const int dyn_lds = getenv("STTFE_WH_DYN_LDS") ? atoi(getenv("STTFE_WH_DYN_LDS")) : 0;
@@ -1299,7 +1347,7 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
 #endif
         hipLaunchKernelGGL(whisper_stft_mel_kernel, dim3(grid), dim3(wh::kThreads), dyn_lds, stream,
                            pcm, offsets, lengths, n_mels, n_frames, tab, out, keys, mask_tbl, n_masks, tiles_per_block,
-                           batch, keys + (size_t)batch * wh::kKeysPerClip, clip_scale, mode, pad_value);
+                           batch, keys + (size_t)batch * wh::kKeysPerClip, clip_scale, mode, pad_value, try_uniform ? 1 : 0);
     }
     {
         ScopedTiming t(kTimeWhisperClamp, stream);

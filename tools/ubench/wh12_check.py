@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Experiment: the 12-wave-per-workgroup Whisper kernel 1 (csrc/whisper_logmel12.inc, `make -C speech_to_text_amd/csrc wh12`)
-against the shipped kernel, both inside tools/ubench/whisper12.so (STTFE_WH12=1 selects the prototype per call):
-bit-identity of the features on uniform and ragged batches, then the kernel times on the headline workload.
-Usage: STTFE_LIB_PATH=$PWD/tools/ubench/whisper12.so python3 tools/ubench/wh12_check.py"""
+"""The 12-wave STFT kernel for uniform batches (csrc/whisper_logmel12.inc) against the general kernel, switched per call with
+sttfe_set_whisper_uniform_kernel: bit-identity of the features on a uniform and on a ragged batch (on the ragged one the
+12-wave kernel returns at once), then both kernels' times on the headline workload.
+Usage: python3 tools/ubench/wh12_check.py   (the commits of DESIGN.md section 4.1.1's experiments need
+STTFE_LIB_PATH=tools/ubench/whisper12.so from `make wh12` there and select the kernel with STTFE_WH12=1)"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -18,7 +19,7 @@ fe = HipWhisperFeatureExtractor(80, device=dev)
 
 
 def run(pcm, off, ln, B, proto):
-    os.environ["STTFE_WH12"] = "1" if proto else "0"
+    assert L.sttfe_set_whisper_uniform_kernel(1 if proto else 0) == 0
     out = torch.full((B, 80, 3000), -7.0, dtype=torch.float32, device=dev)
     fe.extract(pcm, off, ln, out=out)
     torch.cuda.synchronize()
@@ -51,8 +52,8 @@ off = (torch.arange(B, dtype=torch.int64) * 480000).to(dev)
 ln = torch.full((B,), 480000, dtype=torch.int32, device=dev)
 out = torch.empty((B, 80, 3000), dtype=torch.float32, device=dev)
 for proto, tiles in ((0, 0), (1, 21), (1, 7), (1, 9), (1, 63), (0, 0)):
-    os.environ["STTFE_WH12"] = str(proto)
-    os.environ["STTFE_WH12_TILES"] = str(tiles or 21)
+    assert L.sttfe_set_whisper_uniform_kernel(proto) == 0
+    assert L.sttfe_set_whisper_tiles_per_block(tiles) == 0
     L.sttfe_timing_enable(256)
     L.sttfe_timing_set_stride(1 << 30)
     for _ in range(40):
@@ -68,4 +69,6 @@ for proto, tiles in ((0, 0), (1, 21), (1, 7), (1, 9), (1, 63), (0, 0)):
     t2, n2 = ctypes.c_double(), ctypes.c_int()
     L.sttfe_timing_query(b"whisper_clamp_fill", ctypes.byref(t2), ctypes.byref(n2))
     L.sttfe_timing_enable(0)
-    print(f"{'12-wave prototype' if proto else 'shipped kernel   '} tiles/run {tiles:2d}: kernel 1 {t.value / 8:.4f} ms   kernel 2 {t2.value / 8:.4f} ms", flush=True)
+    print(f"{'12-wave kernel   ' if proto else 'general kernel   '} tiles/run {tiles:2d}: kernel 1 {t.value / 8:.4f} ms   kernel 2 {t2.value / 8:.4f} ms", flush=True)
+L.sttfe_set_whisper_tiles_per_block(0)
+L.sttfe_set_whisper_uniform_kernel(1)

@@ -1,16 +1,16 @@
 #!/usr/bin/env python3
-"""Phase times of the specialised-wave prototype (make -C speech_to_text_amd/csrc wh12-stamps):
-STTFE_LIB_PATH=$PWD/tools/ubench/whisper12_stamps.so STTFE_WH12=1 python3 tools/ubench/wh12_stamps.py"""
+"""Phase times of the 12-wave STFT kernel for uniform batches, per wave role (make -C speech_to_text_amd/csrc stamps):
+STTFE_LIB_PATH=$PWD/speech_to_text_amd/libsttfe_stamps.so python3 tools/ubench/wh12_stamps.py"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from speech_to_text_amd import _lib
 from speech_to_text_amd.processors import HipWhisperFeatureExtractor
 from speech_to_text_amd.synth import synth_batch_device
-os.environ["STTFE_WH12"] = "1"
 B = 1024
 dev = torch.device("cuda:0")
 L = _lib.lib()
+assert L.sttfe_set_whisper_uniform_kernel(1) == 0      # the diagnostic builds start with it off
 nblk = 256
 buf = torch.zeros(nblk * 12 * 20, dtype=torch.int64, device=dev)
 L.sttfe_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
