@@ -312,7 +312,9 @@ int sttfe_set_whisper_uniform_kernel(int on);
  * sttfe_timing_enable(capacity) allocates `capacity` event pairs (0 disables and frees them);
  * sttfe_timing_query(name, ...) returns the summed duration and launch count of one kernel
  * ("whisper_stft_mel", "whisper_clamp_fill", "kaldi_fbank", "kaldi_cmvn", "resample_peak",
- * "normalize_trim", "waveform_augment", "pitch_shift") since the last enable/reset; it synchronises on the recorded events.
+ * "normalize_trim", "waveform_augment", "pitch_shift", "whisper_stft_mel12" -- the 12-wave STFT kernel of uniform
+ * batches, launched beside "whisper_stft_mel" by the calls that qualify for it: the one the batch is not for returns at
+ * once) since the last enable/reset; it synchronises on the recorded events.
  */
 int sttfe_timing_enable(int capacity);
 int sttfe_timing_reset(void);

@@ -24,7 +24,8 @@ bool g_enabled = false;
 int g_stride = 1;
 unsigned g_seen[kTimedKernelCount] = {};
 const char* const kNames[kTimedKernelCount] = {"whisper_stft_mel", "whisper_clamp_fill", "kaldi_fbank",
-                                               "kaldi_cmvn", "resample_peak", "normalize_trim", "waveform_augment", "pitch_shift"};
+                                               "kaldi_cmvn", "resample_peak", "normalize_trim", "waveform_augment", "pitch_shift",
+                                               "whisper_stft_mel12"};
 }  // namespace
 
 bool timing_enabled() { return g_enabled; }

@@ -16,7 +16,7 @@ inline bool hip_failed(hipError_t e, const char* what) {
 }
 
 enum TimedKernel { kTimeWhisperStftMel = 0, kTimeWhisperClamp, kTimeKaldiFbank, kTimeKaldiCmvn,
-                   kTimeResample, kTimeNormTrim, kTimeWaveformAug, kTimePitchShift, kTimedKernelCount };
+                   kTimeResample, kTimeNormTrim, kTimeWaveformAug, kTimePitchShift, kTimeWhisperStftMel12, kTimedKernelCount };
 
 bool timing_enabled();
 // Record a start/stop event pair around one launch; returns a slot (or -1 when disabled / full).

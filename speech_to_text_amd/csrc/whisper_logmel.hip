@@ -1330,15 +1330,16 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
     // lengths: whisper_batch_is_uniform); a ragged batch pays one empty launch (~3 us) for it.
     const bool try_uniform = whisper_uniform_kernel_enabled() && n_mels == 80 && mode == wh::kModeHF &&
                              (!mask_tbl || n_masks == 0) && !clip_scale && batch <= 16384 && whisper_uniform_kernel_ready();
+    if (try_uniform) {
+        ScopedTiming t(kTimeWhisperStftMel12, stream);
+        const int cus = current_device_cus();
+        const int grid12 = most_items < cus ? (int)most_items : cus;
+        hipLaunchKernelGGL(whisper_stft_mel12_kernel, dim3(grid12), dim3(wh12::kThreads),
+                           (size_t)wh12::kLdsFloats * sizeof(float), stream, pcm, offsets, lengths, n_frames, tab, out, keys,
+                           batch, tiles_per_block, 1);
+    }
     {
         ScopedTiming t(kTimeWhisperStftMel, stream);
-        if (try_uniform) {
-            const int cus = current_device_cus();
-            const int grid12 = most_items < cus ? (int)most_items : cus;
-            hipLaunchKernelGGL(whisper_stft_mel12_kernel, dim3(grid12), dim3(wh12::kThreads),
-                               (size_t)wh12::kLdsFloats * sizeof(float), stream, pcm, offsets, lengths, n_frames, tab, out, keys,
-                               batch, tiles_per_block, 1);
-        }
 #ifdef STTFE_STAMPS
         // diagnostic build: extra dynamic LDS forces one workgroup per CU (phase times without a co-resident workgroup)
         static const int dyn_lds = getenv("STTFE_WH_DYN_LDS") ? atoi(getenv("STTFE_WH_DYN_LDS")) : 0;

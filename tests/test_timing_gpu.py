@@ -36,6 +36,7 @@ def test_sampled_event_timing_counts_and_durations():
             assert seen == launches and timed == (launches + stride - 1) // stride
             assert 0.0 < ms / timed < 50.0                          # a few microseconds to milliseconds per launch
             assert query(L, b"whisper_clamp_fill")[1:] == (timed, seen)
+            assert query(L, b"whisper_stft_mel12")[1:] == (timed, seen)    # 80 bins, no masks: both STFT kernels are launched
             assert query(L, b"kaldi_fbank")[1:] == (0, 0)
         assert L.sttfe_timing_set_stride(0) == -1
         n = ctypes.c_int()
