@@ -20,6 +20,7 @@ N_CU, N_SIMD, N_SE = 256, 1024, 32          # MI355X: 256 CUs, 4 SIMDs each, 32 
 # resident waves per SIMD of each dominant kernel (launch bounds / LDS), units one wave of it handles, for the per-unit columns
 KERNELS = {
     "whisper_stft_mel_kernel": {"unit": "wave-tile (12 frames)"},
+    "whisper_stft_mel12_kernel": {"unit": "workgroup tile (48 frames)"},
     "kaldi_fbank64_kernel": {"unit": "frame pair"},
     "kaldi_fbank_kernel": {"unit": "wave-tile"},
     "decimate_peak_kernel": {"unit": "wave-tile (256 outputs)"},
@@ -111,12 +112,14 @@ for path in sorted(glob.glob(os.path.join(P, f"{rnd}_*_pmc.json"))):
         out.append(f"- instructions per launch: VALU {g('SQ_INSTS_VALU'):.3g}, SALU {g('SQ_INSTS_SALU'):.3g}, LDS {g('SQ_INSTS_LDS'):.3g}, "
                    f"VMEM read {g('SQ_INSTS_VMEM_RD'):.3g} / write {g('SQ_INSTS_VMEM_WR'):.3g}"
                    + (f", MFMA {g('SQ_INSTS_VALU_MFMA_MOPS_F32') / 4:.3g} (`SQ_INSTS_VALU_MFMA_MOPS_F32 / 4`: a 16x16x4 f32 MFMA counts 4)" if g("SQ_INSTS_VALU_MFMA_MOPS_F32") else ""))
-        if w == "whisper80" and "whisper_stft_mel" in kname:
-            wt = 1024 * 63 * 4                                   # clips x 48-frame tiles x waves: one wave-tile = 12 frames
-            out.append(f"- per wave and tile (`/ (1024 clips x 63 tiles x 4 waves)` = {wt:,}): VALU {g('SQ_INSTS_VALU') / wt:.0f}, SALU {g('SQ_INSTS_SALU') / wt:.0f}, "
-                       f"LDS {g('SQ_INSTS_LDS') / wt:.0f}, VMEM {(g('SQ_INSTS_VMEM_RD') + g('SQ_INSTS_VMEM_WR')) / wt:.0f}, "
-                       f"MFMA {g('SQ_INSTS_VALU_MFMA_MOPS_F32') / 4 / wt:.0f}; {cyc * 2 / 126 / 2:,.0f} cycles per tile of a workgroup "
-                       f"(`cycles / 126 tiles per workgroup`, 512 workgroups)")
+        if w == "whisper80" and "whisper_stft_mel12" in kname:
+            wt = 1024 * 63                                       # clips x 48-frame tiles: one tile of the 12-wave workgroup
+            out.append(f"- per 48-frame tile of a workgroup (`/ (1024 clips x 63 tiles)` = {wt:,}; 8 transform + 4 mel waves): VALU {g('SQ_INSTS_VALU') / wt:.0f}, "
+                       f"SALU {g('SQ_INSTS_SALU') / wt:.0f}, LDS {g('SQ_INSTS_LDS') / wt:.0f}, VMEM {(g('SQ_INSTS_VMEM_RD') + g('SQ_INSTS_VMEM_WR')) / wt:.0f}, "
+                       f"MFMA {g('SQ_INSTS_VALU_MFMA_MOPS_F32') / 4 / wt:.0f}; {cyc / 252:,.0f} cycles per tile of a workgroup "
+                       f"(`cycles / 252 tiles per workgroup`, 256 workgroups)")
+        elif w == "whisper80" and "whisper_stft_mel" in kname:
+            out.append("- (the batch is uniform: this kernel reads the lengths and returns, `whisper_stft_mel12_kernel` computes the call)")
         if g("SQ_ACTIVE_INST_VALU") is not None:
             valu = 4 * g("SQ_ACTIVE_INST_VALU") / (N_SIMD * cyc)
             out.append(f"- VALU pipe busy **{100 * valu:.0f} %** = `4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x cycles)`; "
