@@ -230,3 +230,33 @@ def test_uniform_batches_on_the_12_wave_kernel_are_bit_identical(fe80):
     finally:
         L.sttfe_set_whisper_uniform_kernel(1)
     assert L.sttfe_set_whisper_uniform_kernel(2) == -1 and L.sttfe_set_whisper_uniform_kernel(-1) == -1
+
+
+def test_uniform_kernel_handover_over_many_tiles(fe80):
+    """The 12-wave kernel hands its power panel from the transform waves to the mel waves through two LDS counters (no
+    barrier): 300 full-length clips = 19 k tiles per launch, repeated launches, every run length -- each result bit for
+    bit the general kernel's (tools/ubench/wh12_stress.py is the long version: profiles/r3_wh12_stress.txt)."""
+    from speech_to_text_amd import _lib
+    from speech_to_text_amd.synth import synth_batch_device
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    B = 300
+    pcm = synth_batch_device(9, B, 480000, dev).reshape(-1)
+    off = (torch.arange(B, dtype=torch.int64) * 480000).to(dev)
+    ln = torch.full((B,), 480000, dtype=torch.int32, device=dev)
+    ln[::7] = 476500                                         # still within a tile of 30 s: uniform
+    ref = torch.empty((B, 80, 3000), dtype=torch.float32, device=dev)
+    out = torch.empty_like(ref)
+    try:
+        L.sttfe_set_whisper_uniform_kernel(0)
+        fe80.extract(pcm, off, ln, out=ref)
+        L.sttfe_set_whisper_uniform_kernel(1)
+        for tpb in (0, 1, 4, 21, 63):
+            assert L.sttfe_set_whisper_tiles_per_block(tpb) == 0
+            for _ in range(2):
+                out.fill_(-9.0)
+                fe80.extract(pcm, off, ln, out=out)
+                assert torch.equal(out, ref), tpb
+    finally:
+        L.sttfe_set_whisper_tiles_per_block(0)
+        L.sttfe_set_whisper_uniform_kernel(1)
