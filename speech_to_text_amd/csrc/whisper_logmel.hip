@@ -31,6 +31,9 @@
 //     workspace with one atomic per wave.
 //   Tiles that lie entirely in the padding are left to kernel 2 (they are constant).
 //   Three modes (kMode*): HF semantics, and the two of the reference's TorchWhisperFeatureExtractor.
+// Kernel 1', uniform batches of the 80-bin extractor (stft_mel12, whisper_logmel12.inc): one 768-thread workgroup per CU, eight
+//   transform waves + four mel waves handing the power panel over through LDS counters; same arithmetic, same bits.  Calls
+//   that qualify (HF mode, no masks, no scale) launch both kernels and the lengths on the device decide which one works.
 // Kernel 2 (clamp_fill): 16-32 workgroups per clip, each owning 4-5 interleaved mel rows.  The zero-padding region is filled
 //   with the final constant (write only); of the computed tiles only those whose recorded minimum is below
 //   max - 8 are re-read and clamped to (max - 8 + 4) / 4 (everything else is already final).
