@@ -298,7 +298,7 @@ int sttfe_pitch_shift(float* pcm, const int64_t* offsets, const int32_t* lengths
  * per workgroup otherwise, within [3, 21]).  Tuning knob, no counterpart in the reference. */
 int sttfe_set_whisper_tiles_per_block(int tiles);
 
-/* Uniform batches of the 80-bin extractor (every clip within a 48-frame tile of the longest one: 30 s chunks of
+/* Uniform batches of the 80- and 128-bin extractors (every clip within a 48-frame tile of the longest one: 30 s chunks of
  * long-form audio, padded corpora; HF mode, no masks, no per-clip scale) are computed by a second STFT kernel built for
  * them (one 12-wave workgroup per CU with transform and mel waves, csrc/whisper_logmel12.inc; bit-identical features).
  * on = 1 (default): such calls launch both STFT kernels and the lengths on the device decide which of them works;

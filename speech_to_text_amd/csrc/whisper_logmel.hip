@@ -31,7 +31,7 @@
 //     workspace with one atomic per wave.
 //   Tiles that lie entirely in the padding are left to kernel 2 (they are constant).
 //   Three modes (kMode*): HF semantics, and the two of the reference's TorchWhisperFeatureExtractor.
-// Kernel 1', uniform batches of the 80-bin extractor (stft_mel12, whisper_logmel12.inc): one 768-thread workgroup per CU, eight
+// Kernel 1', uniform batches of the 80- and 128-bin extractors (stft_mel12, whisper_logmel12.inc): one 768-thread workgroup per CU, eight
 //   transform waves + four mel waves handing the power panel over through LDS counters; same arithmetic, same bits.  Calls
 //   that qualify (HF mode, no masks, no scale) launch both kernels and the lengths on the device decide which one works.
 // Kernel 2 (clamp_fill): 16-32 workgroups per clip, each owning 4-5 interleaved mel rows.  The zero-padding region is filled
@@ -1282,9 +1282,11 @@ static bool whisper_uniform_kernel_ready() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
     int st = state[dev].load(std::memory_order_acquire);
     if (st == 0) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(whisper_stft_mel12_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)(wh12::kLdsFloats * sizeof(float)));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(whisper_stft_mel12_kernel<80>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wh12::kLdsFloats * sizeof(float)));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(whisper_stft_mel12_kernel<128>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wh12::kLdsFloats * sizeof(float)));
         if (e != hipSuccess) (void)hipGetLastError();
         st = e == hipSuccess ? 1 : 2;
         state[dev].store(st, std::memory_order_release);
@@ -1327,19 +1329,24 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
     const long most_items = (long)batch * ((n_tiles + 2) / 3);      // fewer workgroups than that cannot all find work
     const int grid = most_items < resident ? (int)most_items : resident;
     const auto* tab = reinterpret_cast<const WhisperTablesHeader*>(dev_tables);
-    // Uniform batches of the 80-bin extractor (HF mode, no masks, no per-clip scale) are computed by
+    // Uniform batches of the 80- and 128-bin extractors (HF mode, no masks, no per-clip scale) are computed by
     // whisper_stft_mel12_kernel (whisper_logmel12.inc).  Whether a batch is uniform is only known on the device, so such a
     // call launches BOTH kernels and each returns at once if the batch is the other's (the same predicate on the same
     // lengths: whisper_batch_is_uniform); a ragged batch pays one empty launch (~3 us) for it.
-    const bool try_uniform = whisper_uniform_kernel_enabled() && n_mels == 80 && mode == wh::kModeHF &&
+    const bool try_uniform = whisper_uniform_kernel_enabled() && (n_mels == 80 || n_mels == 128) && mode == wh::kModeHF &&
                              (!mask_tbl || n_masks == 0) && !clip_scale && batch <= 16384 && whisper_uniform_kernel_ready();
     if (try_uniform) {
         ScopedTiming t(kTimeWhisperStftMel12, stream);
         const int cus = current_device_cus();
         const int grid12 = most_items < cus ? (int)most_items : cus;
-        hipLaunchKernelGGL(whisper_stft_mel12_kernel, dim3(grid12), dim3(wh12::kThreads),
-                           (size_t)wh12::kLdsFloats * sizeof(float), stream, pcm, offsets, lengths, n_frames, tab, out, keys,
-                           batch, tiles_per_block, 1);
+        if (n_mels == 80)
+            hipLaunchKernelGGL(whisper_stft_mel12_kernel<80>, dim3(grid12), dim3(wh12::kThreads),
+                               (size_t)wh12::kLdsFloats * sizeof(float), stream, pcm, offsets, lengths, n_frames, tab, out, keys,
+                               batch, tiles_per_block, 1);
+        else
+            hipLaunchKernelGGL(whisper_stft_mel12_kernel<128>, dim3(grid12), dim3(wh12::kThreads),
+                               (size_t)wh12::kLdsFloats * sizeof(float), stream, pcm, offsets, lengths, n_frames, tab, out, keys,
+                               batch, tiles_per_block, 1);
     }
     {
         ScopedTiming t(kTimeWhisperStftMel, stream);

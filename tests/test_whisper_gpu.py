@@ -201,14 +201,16 @@ def test_mismatched_tables_poison_the_output(fe80, fe128):
         assert bool(torch.isnan(out).all())
 
 
-def test_uniform_batches_on_the_12_wave_kernel_are_bit_identical(fe80):
-    """Uniform batches of the 80-bin extractor (every clip within a tile of the longest, no masks) are computed by
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_uniform_batches_on_the_12_wave_kernel_are_bit_identical(n_mels, fe80, fe128):
+    """Uniform batches of the 80- and 128-bin extractors (every clip within a tile of the longest, no masks) are computed by
     whisper_stft_mel12_kernel; which kernel works is decided on the device from the lengths, by one predicate both kernels
     evaluate.  Same bits as the general kernel (knob off) on full-length, nearly-full-length, short-uniform, empty and
     compact (n_frames < 3000) batches; a ragged batch gives the same bits with the knob on (the 12-wave kernel returns)."""
     from speech_to_text_amd import _lib
     from speech_to_text_amd.processors import pack_clips
     L = _lib.lib()
+    fe = fe80 if n_mels == 80 else fe128
     dev = torch.device("cuda:0")
     cases = [([480000], 3000), ([480000, 479000, 476000, 480000, 473000], 3000), ([480000] * 40, 3000),
              ([16000, 16500, 17000], 3000), ([0, 2, 0], 3000), ([1], 3000), ([480000] * 3, 1000), ([480000, 470000], 52),
@@ -221,8 +223,8 @@ def test_uniform_batches_on_the_12_wave_kernel_are_bit_identical(fe80):
             res = []
             for on in (0, 1):
                 assert L.sttfe_set_whisper_uniform_kernel(on) == 0
-                out = torch.full((len(lens), 80, n_frames), -3.0, dtype=torch.float32, device=dev)
-                fe80.extract(pcm, off, ln, out=out)
+                out = torch.full((len(lens), n_mels, n_frames), -3.0, dtype=torch.float32, device=dev)
+                fe.extract(pcm, off, ln, out=out)
                 torch.cuda.synchronize()
                 res.append(out)
             assert torch.equal(res[0], res[1]), (lens, n_frames)

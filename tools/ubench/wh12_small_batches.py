@@ -12,12 +12,14 @@ from speech_to_text_amd.synth import synth_batch_device
 
 dev = torch.device("cuda:0")
 L = _lib.lib()
-fe = HipWhisperFeatureExtractor(80, device=dev)
+N_MELS = int(sys.argv[1]) if len(sys.argv) > 1 else 80
+fe = HipWhisperFeatureExtractor(N_MELS, device=dev)
+print(f"{N_MELS} mel bins")
 for B in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512):
     pcm = synth_batch_device(3, B, 480000, dev).reshape(-1)
     off = (torch.arange(B, dtype=torch.int64) * 480000).to(dev)
     ln = torch.full((B,), 480000, dtype=torch.int32, device=dev)
-    out = torch.empty((B, 80, 3000), dtype=torch.float32, device=dev)
+    out = torch.empty((B, N_MELS, 3000), dtype=torch.float32, device=dev)
     res = []
     for on in (0, 1):
         L.sttfe_set_whisper_uniform_kernel(on)
