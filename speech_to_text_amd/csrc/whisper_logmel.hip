@@ -422,7 +422,9 @@ __global__ __launch_bounds__(wh::kThreads, STTFE_WH_WAVES_PER_SIMD) void whisper
     if (skip_uniform && whisper_batch_is_uniform(min_len, max_tiles)) return;
     if (tiles_per_block <= 0) {
         const bool uniform = first_pad_tile_of(min_len) + 1 >= max_tiles;
-        tiles_per_block = uniform ? (max_tiles + 2) / 3
+        // (a uniform batch too small to give every workgroup a third of a clip -- a serving batch of a few 30 s chunks --
+        // takes shorter runs, one item per workgroup: one clip was three items on three CUs, 115 us per call)
+        tiles_per_block = uniform ? min((max_tiles + 2) / 3, (batch * max_tiles + (int)gridDim.x - 1) / (int)gridDim.x)
                                   : (sum_tiles > 0 ? sum_tiles / (8 * (int)gridDim.x) : (max_tiles + 4) / 5);
         tiles_per_block = max(3, min(21, tiles_per_block));
     }
@@ -1338,7 +1340,8 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
     if (try_uniform) {
         ScopedTiming t(kTimeWhisperStftMel12, stream);
         const int cus = current_device_cus();
-        const int grid12 = most_items < cus ? (int)most_items : cus;
+        const long tiles12 = (long)batch * n_tiles;                   // (the kernel walks single tiles when the batch is small)
+        const int grid12 = tiles12 < cus ? (int)tiles12 : cus;
         if (n_mels == 80)
             hipLaunchKernelGGL(whisper_stft_mel12_kernel<80>, dim3(grid12), dim3(wh12::kThreads),
                                (size_t)wh12::kLdsFloats * sizeof(float), stream, pcm, offsets, lengths, n_frames, tab, out, keys,
