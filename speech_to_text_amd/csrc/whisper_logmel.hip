@@ -1337,6 +1337,7 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
     // lengths: whisper_batch_is_uniform); a ragged batch pays one empty launch (~3 us) for it.
     const bool try_uniform = whisper_uniform_kernel_enabled() && (n_mels == 80 || n_mels == 128) && mode == wh::kModeHF &&
                              (!mask_tbl || n_masks == 0) && !clip_scale && batch <= 16384 && whisper_uniform_kernel_ready();
+    const bool sure_uniform = try_uniform && batch == 1;      // one clip is a uniform batch whatever its length: no second launch
     if (try_uniform) {
         ScopedTiming t(kTimeWhisperStftMel12, stream);
         const int cus = current_device_cus();
@@ -1345,13 +1346,13 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
         if (n_mels == 80)
             hipLaunchKernelGGL(whisper_stft_mel12_kernel<80>, dim3(grid12), dim3(wh12::kThreads),
                                (size_t)wh12::kLdsFloats * sizeof(float), stream, pcm, offsets, lengths, n_frames, tab, out, keys,
-                               batch, tiles_per_block, 1);
+                               batch, tiles_per_block, sure_uniform ? 0 : 1);
         else
             hipLaunchKernelGGL(whisper_stft_mel12_kernel<128>, dim3(grid12), dim3(wh12::kThreads),
                                (size_t)wh12::kLdsFloats * sizeof(float), stream, pcm, offsets, lengths, n_frames, tab, out, keys,
-                               batch, tiles_per_block, 1);
+                               batch, tiles_per_block, sure_uniform ? 0 : 1);
     }
-    {
+    if (!sure_uniform) {
         ScopedTiming t(kTimeWhisperStftMel, stream);
 #ifdef STTFE_STAMPS
         // diagnostic build: extra dynamic LDS forces one workgroup per CU (phase times without a co-resident workgroup)

@@ -213,7 +213,7 @@ def test_uniform_batches_on_the_12_wave_kernel_are_bit_identical(n_mels, fe80, f
     fe = fe80 if n_mels == 80 else fe128
     dev = torch.device("cuda:0")
     cases = [([480000], 3000), ([480000, 479000, 476000, 480000, 473000], 3000), ([480000] * 40, 3000),
-             ([16000, 16500, 17000], 3000), ([0, 2, 0], 3000), ([1], 3000), ([480000] * 3, 1000), ([480000, 470000], 52),
+             ([16000, 16500, 17000], 3000), ([0, 2, 0], 3000), ([1], 3000), ([250000], 3000), ([7481], 1000), ([480000] * 3, 1000), ([480000, 470000], 52),
              ([480000, 464000, 480000], 3000),                      # two tiles apart: ragged by the rule
              ([480000, 16000, 250000, 1, 7481], 3000)]              # ragged
     try:
