@@ -347,13 +347,28 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # STTFE_BENCH_FORCE_DIST=1: a single rank started by torch.distributed.run still forms its (one-rank) RCCL group, so
+    # that the nccl branch -- group set-up, barriers, the MAX / SUM reductions on device tensors, tear-down -- can be
+    # exercised on a one-GPU box (profiles/r3_bench_rccl_one_rank.json).  Changes nothing that is measured.
+    if world > 1 or os.environ.get("STTFE_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=device)
+            # RCCL prints a version banner on STDOUT when its first communicator comes up; stdout is for the ONE JSON
+            # line, so fd 1 points at stderr while the group forms (the first barrier creates the communicator)
+            sys.stdout.flush()
+            saved_fd = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("nccl", device_id=device)
+                dist.barrier()
+                torch.cuda.synchronize()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved_fd, 1)
+                os.close(saved_fd)
     red_device = torch.device("cpu") if rehearse else device
 
     from speech_to_text_amd import _lib

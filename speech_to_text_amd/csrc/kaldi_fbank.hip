@@ -1013,8 +1013,9 @@ __global__ __launch_bounds__(256) void kaldi_cmvn_seq_kernel(
     constexpr int Q = G / 4;                                            // float4 groups per panel row
     // workgroup -> (clip, column group): consecutive workgroup ids go round the 8 XCDs, so the groups of ONE clip are
     // given ids 8 apart -- they run at the same time on the same XCD and the G-float pieces they read from and write
-    // to each output row meet in one L2.  (Measured neutral on config 2, 0.072 ms either way: the kernel's load, chain
-    // and store phases add up -- 0.031 + 0.017 + 0.025 ms when timed apart -- see DESIGN.md.)
+    // to each output row meet in one L2.  (Measured neutral on config 2.  Round 3, timing-only variants on one box: with
+    // BOTH the panel load and the output store made contiguous the kernel takes 0.0635 instead of 0.0653 ms -- the 32-byte
+    // pieces are not what it waits for; without the chain it takes 0.041 ms: see DESIGN.md 4.3b.)
     const int tid = threadIdx.x, n_groups = n_mels / G;
     const int slot = blockIdx.x >> 3, clip = (slot / n_groups) * 8 + (blockIdx.x & 7);
     if (clip >= batch) return;
@@ -1040,64 +1041,80 @@ __global__ __launch_bounds__(256) void kaldi_cmvn_seq_kernel(
         }
     }
     __syncthreads();
-    // the chain runs in ONE wave of the workgroup; which one rotates with the workgroup index, so that the chains of
-    // the workgroups that share a CU land on different SIMDs instead of queueing on the first
-    const int chain_tid = tid - 64 * (slot & 3);
-    if (chain_tid >= 0 && chain_tid < G) {
-        const float* col = panel + chain_tid;
-        // 32 rows per block: the terms of two rows at a time in packed float32 (independent of the chain, IEEE per
-        // component), then the chain's 32 dependent additions in row order
-        // (the rows of the NEXT block are requested before the current block's additions: read-then-add block by block
-        // left the chain waiting an LDS round trip per block, 17 us of the kernel's 70 on config 2)
+    // The chain runs in ONE wave of the workgroup (which one rotates with the workgroup index, so that the chains of the
+    // workgroups that share a CU land on different SIMDs instead of queueing on the first), on all 64 lanes: lane
+    // 8 c + r holds the term of row t0 + r of column c of an eight-row block, and lane (c, 0) adds the eight terms in row
+    // order with the DPP operand form `v_add_f32 acc, v row_shl:k, acc` -- the same float32 additions in the same order
+    // as NumPy's axis-0 reduction (the other lanes add up values nobody reads).  One LDS read and one term per EIGHT rows
+    // and one dependent instruction per row, where eight lanes that each walked their own column spent a read, a term
+    // and an addition on every row (kaldi_cmvn_seq_kernel 0.077 -> 0.065 ms on config 2).  The accumulator is the plain
+    // operand: a DPP read of a register the previous instruction wrote would cost two wait states per row.
+    const int chain_lane = tid - 64 * (slot & 3);
+    static_assert(G == 8, "lane = 8 c + r: eight columns of eight-row blocks");
+    if (chain_lane >= 0 && chain_lane < 64) {
+        const int c = chain_lane >> 3, r = chain_lane & 7;
+        const float* cell = panel + r * G + c;                        // + t0 * G: 64 consecutive floats per block, no conflicts
+        // v of lane (c, k) brought to lane (c, 0): row_shl:k inside the 16-lane DPP row that holds columns 2 i, 2 i + 1
+        auto from_row = [](float v, auto k) {
+            return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + decltype(k)::value, 0xf, 0xf, true));
+        };
+        const int n_full = T >> 3, rem = T & 7;
         auto sweep = [&](auto&& term) {
             float acc = 0.0f;
-            auto load_block = [&](int t, f32x2 (&x)[16]) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) x[i] = f32x2{col[(t + 2 * i) * G], col[(t + 2 * i + 1) * G]};
+            auto block = [&](float v) {
+                acc = acc + v;
+                acc = acc + from_row(v, std::integral_constant<int, 1>{});
+                acc = acc + from_row(v, std::integral_constant<int, 2>{});
+                acc = acc + from_row(v, std::integral_constant<int, 3>{});
+                acc = acc + from_row(v, std::integral_constant<int, 4>{});
+                acc = acc + from_row(v, std::integral_constant<int, 5>{});
+                acc = acc + from_row(v, std::integral_constant<int, 6>{});
+                acc = acc + from_row(v, std::integral_constant<int, 7>{});
             };
-            auto add_block = [&](const f32x2 (&x)[16]) {
-                f32x2 v[16];
+            int b = 0;
+            // four blocks' rows requested ahead of the four blocks' additions
+            float xa[4], xb[4];
+            auto load4 = [&](int b0, float (&x)[4]) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = term(x[i]);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    acc = acc + v[i].x;
-                    acc = acc + v[i].y;
-                }
+                for (int i = 0; i < 4; ++i) x[i] = cell[(b0 + i) * 8 * G];
             };
-            f32x2 xa[16], xb[16];
-            int t = 0;
-            if (T >= 32) load_block(0, xa);
-            while (t + 32 <= T) {
-                if (t + 64 <= T) load_block(t + 32, xb);
+            if (n_full >= 4) load4(0, xa);
+            while (b + 4 <= n_full) {
+                if (b + 8 <= n_full) load4(b + 4, xb);
                 __builtin_amdgcn_sched_barrier(0);
-                add_block(xa);
-                t += 32;
-                if (t + 32 > T) break;
-                if (t + 64 <= T) load_block(t + 32, xa);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) block(term(xa[i]));
+                b += 4;
+                if (b + 4 > n_full) break;
+                if (b + 8 <= n_full) load4(b + 4, xa);
                 __builtin_amdgcn_sched_barrier(0);
-                add_block(xb);
-                t += 32;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) block(term(xb[i]));
+                b += 4;
             }
-            for (; t < T; ++t) acc = acc + term(f32x2{col[t * G], 0.0f}).x;
-            return acc;
+            for (; b < n_full; ++b) block(term(cell[b * 8 * G]));
+            // the last rows: the missing ones add + 0.0f, which changes no sum (the sums here are never - 0.0f)
+            if (rem) block(r < rem ? term(cell[n_full * 8 * G]) : 0.0f);
+            return __shfl(acc, 8 * c, 64);                            // every lane of column c gets the column's sum
         };
         float mean = 0.0f, sd = 1.0f;
         if (T > 0) {
             const float fT = (float)T;
             // (normalize_means / normalize_vars individually off: see kaldi_stats_seq_kernel)
-            if (!(flags & STTFE_KALDI_NO_MEAN)) mean = sweep([](f32x2 x) { return x; }) / fT;          // x.mean(axis=0)
+            if (!(flags & STTFE_KALDI_NO_MEAN)) mean = sweep([](float x) { return x; }) / fT;             // x.mean(axis=0)
             if (!(flags & STTFE_KALDI_NO_VAR)) {
-                const float arrmean = sweep([mean](f32x2 x) { return x - mean; }) / fT;    // _var: mean of x - mean
-                const float ssq = sweep([mean, arrmean](f32x2 x) {
-                    const f32x2 d = (x - mean) - arrmean;
+                const float arrmean = sweep([mean](float x) { return x - mean; }) / fT;       // _var: mean of x - mean
+                const float ssq = sweep([mean, arrmean](float x) {
+                    const float d = (x - mean) - arrmean;
                     return d * d;
                 });
                 sd = sqrtf(ssq / fT);
             }
         }
-        s_mean[chain_tid] = mean;
-        s_std[chain_tid] = sd;
+        if (r == 0) {
+            s_mean[c] = mean;
+            s_std[c] = sd;
+        }
     }
     __syncthreads();
     int m_axis[STTFE_MAX_MASKS], m_s[STTFE_MAX_MASKS], m_e[STTFE_MAX_MASKS];

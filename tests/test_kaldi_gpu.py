@@ -234,6 +234,20 @@ def test_fused_and_split_cmvn_are_bit_identical_and_long_clips(fe, monkeypatch):
     assert float(np.abs(got - exp).max()) <= TOL
 
 
+def test_fused_cmvn_chain_every_block_remainder(fe, monkeypatch):
+    """The fused kernel's chain wave walks a column in eight-row blocks (a DPP operand per row) with up to seven rows
+    left over, four blocks requested ahead: clips of 1 ... 72 frames (every remainder, with and without full blocks and
+    with and without the look-ahead) must give the bits of the one-thread-per-column kernel pair, which adds row by row."""
+    clips = synth_batch(79, [400 + 160 * (t - 1) for t in range(1, 73)])
+    a = fe(clips, sampling_rate=16000).input_features.cpu()
+    monkeypatch.setenv("STTFE_KALDI_SPLIT_CMVN", "1")
+    b = fe(clips, sampling_rate=16000).input_features.cpu()
+    monkeypatch.delenv("STTFE_KALDI_SPLIT_CMVN")
+    assert a.shape == b.shape and a.shape[1] == 72
+    assert bool(((a == b) | (a.isnan() & b.isnan())).all())
+    assert not a[1:].isnan().any()                                    # (one frame: std 0, NaN as in HF)
+
+
 @pytest.mark.parametrize("mode", ["float64", "float32"])
 @pytest.mark.parametrize("tag,means,varis", [("mean_only", True, False), ("var_only", False, True)])
 def test_cmvn_means_or_vars_alone_match_hf_goldens(mode, tag, means, varis, monkeypatch):
