@@ -1153,6 +1153,186 @@ __global__ __launch_bounds__(256) void kaldi_cmvn_seq_kernel(
     }
 }
 
+// float64 mode, clips of up to 8 NB frames: kaldi_cmvn_seq_kernel's arithmetic with the columns held in REGISTERS.  One
+// wave owns 8 mel columns of one clip; lane 8 c + r keeps rows r, r + 8, r + 16, ... of column c (T / 8 registers), which
+// is exactly the operand the chain wants: block b's term of lane (c, r) is a function of register b, and lane (c, 0) adds
+// the eight terms of a block in row order through the DPP operand (see kaldi_cmvn_seq_kernel).  No LDS panel, so nothing
+// limits residency but registers (NB = 128: 3 waves per SIMD, 3072 waves on the chip -- config 2's 2560 column groups run
+// in ONE round, where the LDS kernel's 32 KB panels forced two rounds that each paid for their longest chain), no
+// barrier, and the loads / chains / stores of different waves overlap freely.
+//   * Memory side: a lane that fetched its own cells would issue T / 8 four-byte loads and as many stores (the address
+//     unit takes a wave instruction four lanes a cycle whatever its width: the loads alone were 0.027 of this kernel's
+//     0.054 ms on config 2).  Instead 16 bytes per lane: lane 2 t + q moves columns 4 q .. 4 q + 3 of row t of a 32-row
+//     piece, loads as `global_load_lds_dwordx4` straight into a wave-private staging slot (two slots of 128 rows: the
+//     next chunk is in flight while this one is dealt to the (c, r) registers with conflict-free ds_read), stores from
+//     the same slots (ds_write by (c, r), ds_read_b128 + global_store_dwordx4 by (t, q)).
+//   * The division by the deviation is the compiler's own IEEE sequence with the parts that depend on the divisor alone
+//     (reciprocal and its refinement) taken out of the loop -- valid where v_div_scale would not scale, which a
+//     wave-uniform test on the deviation and the mean guarantees (see `fast`); otherwise the plain division.
+// Same additions in the same order, same quotients: the three forms (this, the LDS form, the split pair) are
+// bit-identical (tests/test_kaldi_gpu.py).
+template <int NB>
+__global__ __launch_bounds__(64, 12) void kaldi_cmvn_reg_kernel(
+    float* __restrict__ out, const int32_t* __restrict__ lengths, int batch, int n_mels, int t_max, int max_frames,
+    void* __restrict__ attn, int attn_bytes, const int32_t* __restrict__ mask_tbl, int n_masks,
+    const KaldiTablesHeader* __restrict__ tab, int flags) {
+#pragma clang fp contract(off)
+    constexpr int G = 8, kChunks = NB / 16;                           // a chunk = 16 blocks = 128 rows = four 32-row pieces
+    static_assert(NB % 16 == 0, "whole chunks");
+    __shared__ __attribute__((aligned(16))) float stage[2][128 * G];
+    const int lane = threadIdx.x, c = lane >> 3, r = lane & 7;        // chain side: (column, row of the block)
+    const int tq = lane >> 1, q = lane & 1;                           // memory side: (row of the piece, column quad)
+    // workgroup -> (clip, column group) as in kaldi_cmvn_seq_kernel: the groups of one clip run on one XCD
+    const int n_groups = n_mels / G;
+    const int slot = blockIdx.x >> 3, clip = (slot / n_groups) * 8 + (blockIdx.x & 7);
+    if (clip >= batch) return;
+    const int g0 = (slot % n_groups) * G;
+    const size_t row = (size_t)n_mels;
+    float* __restrict__ base = out + (size_t)clip * t_max * n_mels + g0;       // (row 0, column g0)
+    float* __restrict__ mine = base + 4 * q;                                  // memory side, + row * n_mels
+    if (tab->magic != kKaldiMagic || tab->n_mels != n_mels) {
+        const float nan = __builtin_nanf("");                                 // see sttfe.h
+        for (int t = tq; t < t_max; t += 32) *reinterpret_cast<f32x4*>(mine + (size_t)t * row) = f32x4{nan, nan, nan, nan};
+        return;
+    }
+    const int T = kaldi_num_frames(lengths[clip], max_frames, t_max);
+    const int n_full = T >> 3, rem = T & 7;
+    const int n_chunks_in = (T + 127) >> 7;
+    // the rows left over after the full blocks, in a register of their own (requested first: the waits below count DMAs)
+    const float xt = (r < rem) ? base[(size_t)(n_full * 8 + r) * row + c] : 0.0f;
+    auto dma_chunk = [&](int ch, float* dst) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = min(128 * ch + 32 * i + tq, t_max - 1);             // (rows past the clip are never used)
+            __builtin_amdgcn_global_load_lds(mine + (size_t)t * row, dst + 256 * i, 16, 0, 0);
+        }
+    };
+    if (n_chunks_in > 0) dma_chunk(0, stage[0]);
+    if (n_chunks_in > 1) dma_chunk(1, stage[1]);
+    float x[NB];
+#pragma unroll
+    for (int ch = 0; ch < kChunks; ++ch) {
+        if (ch < n_chunks_in) {
+            // loads land in order: chunk ch is in LDS once at most the four DMAs of chunk ch + 1 are outstanding
+            // (nothing else orders a ds_read behind a pending DMA)
+            if (ch + 1 < n_chunks_in) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const float* sl = stage[ch & 1] + r * G + c;                      // 64 consecutive floats per block: no conflicts
+#pragma unroll
+            for (int bb = 0; bb < 16; ++bb) x[16 * ch + bb] = sl[bb * 8 * G];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the slot is read before it is refilled
+            if (ch + 2 < n_chunks_in) dma_chunk(ch + 2, stage[ch & 1]);
+        }
+    }
+    auto from_row = [](float v, auto k) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + decltype(k)::value, 0xf, 0xf, true));
+    };
+    auto sweep = [&](auto&& term) {
+        float acc = 0.0f;
+        auto block = [&](float v) {
+            acc = acc + v;
+            acc = acc + from_row(v, std::integral_constant<int, 1>{});
+            acc = acc + from_row(v, std::integral_constant<int, 2>{});
+            acc = acc + from_row(v, std::integral_constant<int, 3>{});
+            acc = acc + from_row(v, std::integral_constant<int, 4>{});
+            acc = acc + from_row(v, std::integral_constant<int, 5>{});
+            acc = acc + from_row(v, std::integral_constant<int, 6>{});
+            acc = acc + from_row(v, std::integral_constant<int, 7>{});
+        };
+#pragma unroll
+        for (int k = 0; k < kChunks; ++k) {
+            if (16 * k < n_full) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (16 * k + i < n_full) block(term(x[16 * k + i]));
+            }
+        }
+        // the last rows: the missing ones add + 0.0f, which changes no sum (the sums here are never - 0.0f)
+        if (rem) block(r < rem ? term(xt) : 0.0f);
+        return __shfl(acc, 8 * c, 64);                                // every lane of column c gets the column's sum
+    };
+    float mean = 0.0f, sd = 1.0f;
+    if (T > 0) {
+        const float fT = (float)T;
+        // (normalize_means / normalize_vars individually off: see kaldi_stats_seq_kernel)
+        if (!(flags & STTFE_KALDI_NO_MEAN)) mean = sweep([](float v) { return v; }) / fT;                 // x.mean(axis=0)
+        if (!(flags & STTFE_KALDI_NO_VAR)) {
+            const float arrmean = sweep([mean](float v) { return v - mean; }) / fT;           // _var: mean of x - mean
+            const float ssq = sweep([mean, arrmean](float v) {
+                const float d = (v - mean) - arrmean;
+                return d * d;
+            });
+            sd = sqrtf(ssq / fT);
+        }
+    }
+    // (x - mean) / sd.  The compiler's float32 division is: sb = div_scale(sd), sn = div_scale(n), r0 = rcp(sb),
+    // rp = fma(fma(-sb, r0, 1), r0, r0), q = sn rp, q1 = fma(fma(-sb, q, sn), rp, q), fma(fma(-sb, q1, sn), rp, q1), then
+    // div_fmas / div_fixup, which undo the scaling and patch zero / infinite / NaN operands.  v_div_scale leaves both
+    // operands alone unless the divisor is denormal or huge, the numerator below 2^-103 or the exponents 96 apart: with
+    // 2^-30 <= sd, |mean| <= 2^30 in every lane a non-zero numerator x - mean is at least 2^-55 (x within a factor two
+    // of the mean: the difference is a multiple of the smaller ulp; otherwise it is at least half the mean) and at most
+    // about sd sqrt(T) <= 2^35 (each squared deviation is a term of the sum under the root; with normalize_vars off
+    // sd is 1 and both sequences return the numerator itself), and a zero numerator is + 0 and stays + 0 through the
+    // sequence -- so there the reciprocal part is taken out of the loop and five instructions per cell remain, with
+    // the bits of the full sequence.
+    const float kLo = 9.31322574615478515625e-10f, kHi = 1073741824.0f;        // 2^-30, 2^30
+    const bool fast = __all(sd >= kLo && sd <= kHi && fabsf(mean) >= kLo && fabsf(mean) <= kHi);
+    const float r0 = __builtin_amdgcn_rcpf(sd);
+    const float rp = __builtin_fmaf(__builtin_fmaf(-sd, r0, 1.0f), r0, r0);
+    auto norm = [&](float xv, auto is_fast) {
+        const float n = xv - mean;
+        if constexpr (decltype(is_fast)::value) {
+            const float q0 = n * rp;
+            const float q1 = __builtin_fmaf(__builtin_fmaf(-sd, q0, n), rp, q0);
+            return __builtin_fmaf(__builtin_fmaf(-sd, q1, n), rp, q1);
+        } else {
+            return n / sd;
+        }
+    };
+    // SpecAugment: a masked mel column is zero from top to bottom (chain side), a masked frame on the memory side
+    const int nm = mask_tbl ? (n_masks > STTFE_MAX_MASKS ? STTFE_MAX_MASKS : n_masks) : 0;
+    bool col_masked = false;
+    for (int i = 0; i < nm; ++i) {
+        const int32_t* m = mask_tbl + ((size_t)clip * n_masks + i) * 3;
+        if (m[0] != STTFE_AXIS_TIME && g0 + c >= m[1] && g0 + c < m[2]) col_masked = true;
+    }
+    auto store_all = [&](auto is_fast) {
+        const float yt = (r < rem && !col_masked) ? norm(xt, is_fast) : 0.0f;
+#pragma unroll
+        for (int ch = 0; ch < kChunks; ++ch) {
+            if (128 * ch < t_max) {
+                float* sl = stage[ch & 1] + r * G + c;                        // (LDS runs a wave's operations in order)
+#pragma unroll
+                for (int bb = 0; bb < 16; ++bb) {
+                    const int b = 16 * ch + bb;
+                    float y = 0.0f;                                           // rows past the clip: padding
+                    if (b < n_full) y = col_masked ? 0.0f : norm(x[b], is_fast);
+                    else if (b == n_full) y = yt;
+                    sl[bb * 8 * G] = y;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int t = 128 * ch + 32 * i + tq;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stage[ch & 1] + 256 * i + 4 * lane);
+                    for (int k = 0; k < nm; ++k) {
+                        const int32_t* m = mask_tbl + ((size_t)clip * n_masks + k) * 3;
+                        if (m[0] == STTFE_AXIS_TIME && t >= m[1] && t < m[2]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    if (t < t_max) *reinterpret_cast<f32x4*>(mine + (size_t)t * row) = v;
+                }
+            }
+        }
+    };
+    if (fast) store_all(std::true_type{});
+    else store_all(std::false_type{});
+    if (attn && g0 == 0) {
+        for (int t = lane; t < t_max; t += 64) {
+            if (attn_bytes == 8) reinterpret_cast<int64_t*>(attn)[(size_t)clip * t_max + t] = t < T ? 1 : 0;
+            else reinterpret_cast<int32_t*>(attn)[(size_t)clip * t_max + t] = t < T ? 1 : 0;
+        }
+    }
+}
+
 }  // namespace sttfe
 
 using namespace sttfe;
@@ -1228,7 +1408,14 @@ extern "C" int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, 
         const bool seq_split = getenv("STTFE_KALDI_SPLIT_CMVN") != nullptr;     // A/B and test knob: the two-kernel form
         const size_t panel_bytes = (size_t)t_max * kG * sizeof(float);
         const bool f64_cmvn = (flags & STTFE_KALDI_F64) && !(flags & STTFE_KALDI_NO_CMVN);
-        if (f64_cmvn && !seq_split && n_mels % kG == 0 && panel_bytes <= 64 * 1024 &&
+        const bool lds_form = getenv("STTFE_KALDI_LDS_CMVN") != nullptr;        // A/B and test knob: the LDS-panel form
+        constexpr int kRegBlocks = 128;
+        if (f64_cmvn && !seq_split && !lds_form && n_mels % 8 == 0 && t_max <= 8 * kRegBlocks &&
+            (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+            hipLaunchKernelGGL(kaldi_cmvn_reg_kernel<kRegBlocks>, dim3((batch + 7) / 8 * 8 * (n_mels / 8)), dim3(64), 0,
+                               stream, out, lengths, batch, n_mels, t_max, max_frames, attn_mask, attn_mask_bytes,
+                               mask_tbl, n_masks, tab, flags);
+        } else if (f64_cmvn && !seq_split && n_mels % kG == 0 && panel_bytes <= 64 * 1024 &&
             (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
             hipLaunchKernelGGL(kaldi_cmvn_seq_kernel<kG>, dim3((batch + 7) / 8 * 8 * (n_mels / kG)), dim3(256), panel_bytes,
                                stream, out, lengths, batch, n_mels, t_max, max_frames, attn_mask, attn_mask_bytes,

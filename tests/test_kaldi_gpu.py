@@ -235,17 +235,31 @@ def test_fused_and_split_cmvn_are_bit_identical_and_long_clips(fe, monkeypatch):
 
 
 def test_fused_cmvn_chain_every_block_remainder(fe, monkeypatch):
-    """The fused kernel's chain wave walks a column in eight-row blocks (a DPP operand per row) with up to seven rows
-    left over, four blocks requested ahead: clips of 1 ... 72 frames (every remainder, with and without full blocks and
-    with and without the look-ahead) must give the bits of the one-thread-per-column kernel pair, which adds row by row."""
+    """The fused CMVN kernels (columns in registers for clips of up to 1024 frames, the LDS-panel form up to 2048) walk a
+    column in eight-row blocks (a DPP operand per row) with up to seven rows left over: clips of 1 ... 72 frames (every
+    remainder, with and without full blocks, across the sixteen-block groups and the LDS form's look-ahead) must give the
+    bits of the one-thread-per-column kernel pair, which adds row by row.  With SpecAugment masks on both axes too."""
     clips = synth_batch(79, [400 + 160 * (t - 1) for t in range(1, 73)])
-    a = fe(clips, sampling_rate=16000).input_features.cpu()
-    monkeypatch.setenv("STTFE_KALDI_SPLIT_CMVN", "1")
-    b = fe(clips, sampling_rate=16000).input_features.cpu()
-    monkeypatch.delenv("STTFE_KALDI_SPLIT_CMVN")
-    assert a.shape == b.shape and a.shape[1] == 72
-    assert bool(((a == b) | (a.isnan() & b.isnan())).all())
-    assert not a[1:].isnan().any()                                    # (one frame: std 0, NaN as in HF)
+    masks = torch.zeros((len(clips), 3, 3), dtype=torch.int32)       # axis 1 = time, 0 = mel (as in the test above)
+    masks[:, 0] = torch.tensor([1, 3, 21])
+    masks[:, 1] = torch.tensor([0, 7, 18])
+    masks[:, 2] = torch.tensor([1, 60, 90])
+    for m in (None, masks):
+        outs = {}
+        for knob in (None, "STTFE_KALDI_LDS_CMVN", "STTFE_KALDI_SPLIT_CMVN"):
+            if knob:
+                monkeypatch.setenv(knob, "1")
+            o = fe(clips, sampling_rate=16000, mask_table=m) if m is not None else fe(clips, sampling_rate=16000)
+            outs[knob] = (o.input_features.cpu(), o.attention_mask.cpu())
+            if knob:
+                monkeypatch.delenv(knob)
+        a, am = outs[None]
+        assert a.shape[1] == 72
+        for knob in ("STTFE_KALDI_LDS_CMVN", "STTFE_KALDI_SPLIT_CMVN"):
+            b, bm = outs[knob]
+            assert a.shape == b.shape and bool(((a == b) | (a.isnan() & b.isnan())).all()), knob
+            assert bool((am == bm).all())
+        assert not a[1:].isnan().any()                                # (one frame: std 0, NaN as in HF)
 
 
 @pytest.mark.parametrize("mode", ["float64", "float32"])
