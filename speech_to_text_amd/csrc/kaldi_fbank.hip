@@ -1171,17 +1171,18 @@ __global__ __launch_bounds__(256) void kaldi_cmvn_seq_kernel(
 //     wave-uniform test on the deviation and the mean guarantees (see `fast`); otherwise the plain division.
 // Same additions in the same order, same quotients: the three forms (this, the LDS form, the split pair) are
 // bit-identical (tests/test_kaldi_gpu.py).
-template <int NB>
-__global__ __launch_bounds__(64, 12) void kaldi_cmvn_reg_kernel(
+template <int G, int NB>
+__global__ __launch_bounds__(64, NB <= 128 ? 12 : 8) void kaldi_cmvn_reg_kernel(
     float* __restrict__ out, const int32_t* __restrict__ lengths, int batch, int n_mels, int t_max, int max_frames,
     void* __restrict__ attn, int attn_bytes, const int32_t* __restrict__ mask_tbl, int n_masks,
     const KaldiTablesHeader* __restrict__ tab, int flags) {
 #pragma clang fp contract(off)
-    constexpr int G = 8, kChunks = NB / 16;                           // a chunk = 16 blocks = 128 rows = four 32-row pieces
-    static_assert(NB % 16 == 0, "whole chunks");
-    __shared__ __attribute__((aligned(16))) float stage[2][128 * G];
-    const int lane = threadIdx.x, c = lane >> 3, r = lane & 7;        // chain side: (column, row of the block)
-    const int tq = lane >> 1, q = lane & 1;                           // memory side: (row of the piece, column quad)
+    // G = 8 columns in blocks of R = 8 rows, or (longer clips: T / R registers) G = 4 columns in blocks of R = 16 rows
+    constexpr int R = 64 / G, Q = G / 4, kPieceRows = 64 / Q, kChunkRows = 4 * kPieceRows, kChunks = NB / 16;
+    static_assert((G == 8 || G == 4) && NB % 16 == 0 && kChunkRows == 16 * R, "a chunk = four 1 KB pieces = 16 blocks");
+    __shared__ __attribute__((aligned(16))) float stage[2][1024];
+    const int lane = threadIdx.x, c = lane / R, r = lane % R;         // chain side: (column, row of the block)
+    const int tq = lane / Q, q = lane % Q;                            // memory side: (row of the piece, column quad)
     // workgroup -> (clip, column group) as in kaldi_cmvn_seq_kernel: the groups of one clip run on one XCD
     const int n_groups = n_mels / G;
     const int slot = blockIdx.x >> 3, clip = (slot / n_groups) * 8 + (blockIdx.x & 7);
@@ -1192,18 +1193,18 @@ __global__ __launch_bounds__(64, 12) void kaldi_cmvn_reg_kernel(
     float* __restrict__ mine = base + 4 * q;                                  // memory side, + row * n_mels
     if (tab->magic != kKaldiMagic || tab->n_mels != n_mels) {
         const float nan = __builtin_nanf("");                                 // see sttfe.h
-        for (int t = tq; t < t_max; t += 32) *reinterpret_cast<f32x4*>(mine + (size_t)t * row) = f32x4{nan, nan, nan, nan};
+        for (int t = tq; t < t_max; t += kPieceRows) *reinterpret_cast<f32x4*>(mine + (size_t)t * row) = f32x4{nan, nan, nan, nan};
         return;
     }
     const int T = kaldi_num_frames(lengths[clip], max_frames, t_max);
-    const int n_full = T >> 3, rem = T & 7;
-    const int n_chunks_in = (T + 127) >> 7;
+    const int n_full = T / R, rem = T % R;
+    const int n_chunks_in = (T + kChunkRows - 1) / kChunkRows;
     // the rows left over after the full blocks, in a register of their own (requested first: the waits below count DMAs)
-    const float xt = (r < rem) ? base[(size_t)(n_full * 8 + r) * row + c] : 0.0f;
+    const float xt = (r < rem) ? base[(size_t)(n_full * R + r) * row + c] : 0.0f;
     auto dma_chunk = [&](int ch, float* dst) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int t = min(128 * ch + 32 * i + tq, t_max - 1);             // (rows past the clip are never used)
+            const int t = min(kChunkRows * ch + kPieceRows * i + tq, t_max - 1);      // (rows past the clip are never used)
             __builtin_amdgcn_global_load_lds(mine + (size_t)t * row, dst + 256 * i, 16, 0, 0);
         }
     };
@@ -1219,7 +1220,7 @@ __global__ __launch_bounds__(64, 12) void kaldi_cmvn_reg_kernel(
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const float* sl = stage[ch & 1] + r * G + c;                      // 64 consecutive floats per block: no conflicts
 #pragma unroll
-            for (int bb = 0; bb < 16; ++bb) x[16 * ch + bb] = sl[bb * 8 * G];
+            for (int bb = 0; bb < 16; ++bb) x[16 * ch + bb] = sl[bb * 64];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the slot is read before it is refilled
             if (ch + 2 < n_chunks_in) dma_chunk(ch + 2, stage[ch & 1]);
         }
@@ -1238,6 +1239,16 @@ __global__ __launch_bounds__(64, 12) void kaldi_cmvn_reg_kernel(
             acc = acc + from_row(v, std::integral_constant<int, 5>{});
             acc = acc + from_row(v, std::integral_constant<int, 6>{});
             acc = acc + from_row(v, std::integral_constant<int, 7>{});
+            if constexpr (R == 16) {
+                acc = acc + from_row(v, std::integral_constant<int, 8>{});
+                acc = acc + from_row(v, std::integral_constant<int, 9>{});
+                acc = acc + from_row(v, std::integral_constant<int, 10>{});
+                acc = acc + from_row(v, std::integral_constant<int, 11>{});
+                acc = acc + from_row(v, std::integral_constant<int, 12>{});
+                acc = acc + from_row(v, std::integral_constant<int, 13>{});
+                acc = acc + from_row(v, std::integral_constant<int, 14>{});
+                acc = acc + from_row(v, std::integral_constant<int, 15>{});
+            }
         };
 #pragma unroll
         for (int k = 0; k < kChunks; ++k) {
@@ -1249,7 +1260,7 @@ __global__ __launch_bounds__(64, 12) void kaldi_cmvn_reg_kernel(
         }
         // the last rows: the missing ones add + 0.0f, which changes no sum (the sums here are never - 0.0f)
         if (rem) block(r < rem ? term(xt) : 0.0f);
-        return __shfl(acc, 8 * c, 64);                                // every lane of column c gets the column's sum
+        return __shfl(acc, R * c, 64);                                // every lane of column c gets the column's sum
     };
     float mean = 0.0f, sd = 1.0f;
     if (T > 0) {
@@ -1300,7 +1311,7 @@ __global__ __launch_bounds__(64, 12) void kaldi_cmvn_reg_kernel(
         const float yt = (r < rem && !col_masked) ? norm(xt, is_fast) : 0.0f;
 #pragma unroll
         for (int ch = 0; ch < kChunks; ++ch) {
-            if (128 * ch < t_max) {
+            if (kChunkRows * ch < t_max) {
                 float* sl = stage[ch & 1] + r * G + c;                        // (LDS runs a wave's operations in order)
 #pragma unroll
                 for (int bb = 0; bb < 16; ++bb) {
@@ -1308,11 +1319,11 @@ __global__ __launch_bounds__(64, 12) void kaldi_cmvn_reg_kernel(
                     float y = 0.0f;                                           // rows past the clip: padding
                     if (b < n_full) y = col_masked ? 0.0f : norm(x[b], is_fast);
                     else if (b == n_full) y = yt;
-                    sl[bb * 8 * G] = y;
+                    sl[bb * 64] = y;
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int t = 128 * ch + 32 * i + tq;
+                    const int t = kChunkRows * ch + kPieceRows * i + tq;
                     f32x4 v = *reinterpret_cast<const f32x4*>(stage[ch & 1] + 256 * i + 4 * lane);
                     for (int k = 0; k < nm; ++k) {
                         const int32_t* m = mask_tbl + ((size_t)clip * n_masks + k) * 3;
@@ -1409,12 +1420,18 @@ extern "C" int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, 
         const size_t panel_bytes = (size_t)t_max * kG * sizeof(float);
         const bool f64_cmvn = (flags & STTFE_KALDI_F64) && !(flags & STTFE_KALDI_NO_CMVN);
         const bool lds_form = getenv("STTFE_KALDI_LDS_CMVN") != nullptr;        // A/B and test knob: the LDS-panel form
-        constexpr int kRegBlocks = 128;
-        if (f64_cmvn && !seq_split && !lds_form && n_mels % 8 == 0 && t_max <= 8 * kRegBlocks &&
-            (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
-            hipLaunchKernelGGL(kaldi_cmvn_reg_kernel<kRegBlocks>, dim3((batch + 7) / 8 * 8 * (n_mels / 8)), dim3(64), 0,
-                               stream, out, lengths, batch, n_mels, t_max, max_frames, attn_mask, attn_mask_bytes,
-                               mask_tbl, n_masks, tab, flags);
+        // columns in registers: 8 columns x blocks of 8 rows up to 1024 frames, 4 columns x blocks of 16 rows up to 3072
+        const bool reg_ok = f64_cmvn && !seq_split && !lds_form && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+        auto launch_reg = [&](auto kern, int g) {
+            hipLaunchKernelGGL(kern, dim3((batch + 7) / 8 * 8 * (n_mels / g)), dim3(64), 0, stream, out, lengths, batch,
+                               n_mels, t_max, max_frames, attn_mask, attn_mask_bytes, mask_tbl, n_masks, tab, flags);
+        };
+        if (reg_ok && n_mels % 8 == 0 && t_max <= 8 * 128) {
+            launch_reg(kaldi_cmvn_reg_kernel<8, 128>, 8);
+        } else if (reg_ok && n_mels % 4 == 0 && t_max <= 16 * 128) {
+            launch_reg(kaldi_cmvn_reg_kernel<4, 128>, 4);
+        } else if (reg_ok && n_mels % 4 == 0 && t_max <= 16 * 192) {
+            launch_reg(kaldi_cmvn_reg_kernel<4, 192>, 4);
         } else if (f64_cmvn && !seq_split && n_mels % kG == 0 && panel_bytes <= 64 * 1024 &&
             (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
             hipLaunchKernelGGL(kaldi_cmvn_seq_kernel<kG>, dim3((batch + 7) / 8 * 8 * (n_mels / kG)), dim3(256), panel_bytes,

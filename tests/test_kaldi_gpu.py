@@ -227,11 +227,21 @@ def test_fused_and_split_cmvn_are_bit_identical_and_long_clips(fe, monkeypatch):
     monkeypatch.delenv("STTFE_KALDI_SPLIT_CMVN")
     assert bool(((a == b) | (a.isnan() & b.isnan())).all())           # the one-frame clip has std 0: NaN, as in HF
     assert not a[:3].isnan().any()
-    long_clip = synth_batch(78, [432000])                            # 2698 frames: beyond the fused kernel's panel
+    long_clip = synth_batch(78, [432000])                            # 2698 frames: beyond the LDS form's panel
     got = fe(long_clip, sampling_rate=16000).input_features.cpu().numpy()
     exp, _, tl = speech2text_features(long_clip)
     assert got.shape == exp.shape and tl[0] == 2698
     assert float(np.abs(got - exp).max()) <= TOL
+    # the register form's three shapes (8 columns x 8-row blocks up to 1024 frames, 4 columns x 16-row blocks up to 2048
+    # and up to 3072) against the split pair, and a 32 s clip that only the split pair takes
+    for seed, lens in ((80, [163600, 99999, 16000]), (81, [250000, 327680, 40000, 399]), (82, [432000, 491520, 70001]),
+                       (83, [512000, 16000])):
+        clips = synth_batch(seed, lens)
+        a = fe(clips, sampling_rate=16000).input_features.cpu()
+        monkeypatch.setenv("STTFE_KALDI_SPLIT_CMVN", "1")
+        b = fe(clips, sampling_rate=16000).input_features.cpu()
+        monkeypatch.delenv("STTFE_KALDI_SPLIT_CMVN")
+        assert a.shape == b.shape and bool(((a == b) | (a.isnan() & b.isnan())).all()), lens
 
 
 def test_fused_cmvn_chain_every_block_remainder(fe, monkeypatch):
