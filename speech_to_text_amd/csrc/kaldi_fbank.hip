@@ -93,7 +93,7 @@ struct KaldiItems {
 // Called by all 256 threads of the workgroup (contains barriers).  `plan` has kKaldiPlanClips + 1 ints, `scratch` 4.
 __device__ __forceinline__ KaldiItems kaldi_build_items(int* plan, int* scratch, const int32_t* __restrict__ lengths,
                                                        int batch, int t_max, int max_frames, int tiles_per_block,
-                                                       int n_runs_dense, int n_items_dense) {
+                                                       int n_runs_dense, int n_items_dense, int tile_frames = kaldi::kTileFrames) {
     KaldiItems it{plan, n_items_dense, n_runs_dense, batch, batch <= kKaldiPlanClips};
     if (!it.planned) return it;
     constexpr int kPer = kKaldiPlanClips / kaldi::kThreads;
@@ -108,7 +108,7 @@ __device__ __forceinline__ KaldiItems kaldi_build_items(int* plan, int* scratch,
         before[k] = sum;
         if (k < per && tid * per + k < batch) {
             const int T = kaldi_num_frames(lens[k], max_frames, t_max);
-            const int tiles = (T + kaldi::kTileFrames - 1) / kaldi::kTileFrames;
+            const int tiles = (T + tile_frames - 1) / tile_frames;
             sum += (tiles + tiles_per_block - 1) / tiles_per_block;                        // 0 for a clip without a frame
         }
     }
@@ -488,8 +488,6 @@ __global__ __launch_bounds__(kaldi::kThreads, 2) void kaldi_fbank_kernel(
 namespace kaldi64 {
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
-constexpr int kTileFrames = 32;
-constexpr int kFramesPerWave = 8;
 constexpr int kHop = 160;
 constexpr int kFrame = 400;
 constexpr int kPowStride = 258;            // doubles per power row (257 bins)
@@ -584,20 +582,29 @@ __global__ __launch_bounds__(kaldi64::kThreads, kaldi64::kWgPerCu) void kaldi_fb
     const float* __restrict__ pcm, const int64_t* __restrict__ offsets,
     const int32_t* __restrict__ lengths, int n_mels, int t_max, int max_frames,
     const KaldiTablesHeader* __restrict__ tab, float* __restrict__ out,
-    int tiles_per_block, int n_runs, int n_items, unsigned* __restrict__ ticket, int batch) {
+    int n_runs, int n_items, int batch, int item_frames) {
     using namespace kaldi64;
     __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsBytes];
-    __shared__ unsigned s_next[2];
     __shared__ int s_plan[kKaldiPlanClips + 1], s_scan[4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tab->magic != kKaldiMagic || tab->n_mels != n_mels) return;      // the CMVN pass poisons the output
-    const KaldiItems items = kaldi_build_items(s_plan, s_scan, lengths, batch, t_max, max_frames, tiles_per_block, n_runs, n_items);
+    // Items belong to WAVES, not workgroups: an item is item_frames consecutive frames of one clip (1, 2, 4 ... frame
+    // pairs; the host picks few pairs for small batches) and wave w of the launch takes items w, w + waves, w + 2 waves,
+    // ... of the compacted item space -- nothing in the item loop is collective (no barrier, no LDS hand-over) and there
+    // is no ticket: the items cost the same, so striding balances them to within one item, and one counter serves only
+    // ~88 tickets per microsecond (3072 waves asking for one-pair items: 0.85 ms for config 2 instead of 0.17).  With
+    // workgroup-wide items of 32 frames config 2 gave a workgroup 6.25 items: the kernel ended when those with seven
+    // did, and smaller workgroup-wide items paid a barrier per frame pair (256 clips: 0.173 ms whatever the size).
+    // (the host launches this kernel on at most kKaldiPlanClips clips at a time: striding needs the compacted item space --
+    // over dense items a stride that is a multiple of n_runs would pin a wave to one run index, mostly past the clips' ends)
+    const KaldiItems items = kaldi_build_items(s_plan, s_scan, lengths, batch, t_max, max_frames, 1, n_runs, n_items, item_frames);
     n_items = items.n_items;
-    int item = blockIdx.x;
-    if (item >= n_items) return;
+    const int n_workers = (int)gridDim.x * kWaves;
+    int item = (int)blockIdx.x * kWaves + wave;
+    if ((int)blockIdx.x * kWaves >= n_items) return;                   // (the whole workgroup: there is a barrier below)
 
     // float64 section of the tables blob: window[400], W512 (cos, -sin)[512], then the mel bands and their weights
     const double* __restrict__ t64 = reinterpret_cast<const double*>(
@@ -633,17 +640,20 @@ __global__ __launch_bounds__(kaldi64::kThreads, kaldi64::kWgPerCu) void kaldi_fb
     const double2k* ltab = reinterpret_cast<const double2k*>(smem + kLogOff);
     const int mel_rounds = (2 * n_mels + 63) >> 6;
 
-    // items: as in kaldi_fbank_kernel (two static items, then tickets; the next item's clip, length and offset are
-    // requested at the top of the current item)
-    unsigned iter = 0, my_ticket = 0;
-    int next_item = min((int)(blockIdx.x + gridDim.x), n_items);
+    // the next item's clip, length and offset are requested at the top of the current item
+    if (item >= n_items) return;                                      // (per wave: nothing below is collective)
+    int next_item = min(item + n_workers, n_items);
     int clip_cur, run_cur, clip_nx = 0, run_nx = 0;
     kaldi_decode_item(items, item, clip_cur, run_cur);
     if (next_item < n_items) kaldi_decode_item(items, next_item, clip_nx, run_nx);
     int len_cur = lengths[clip_cur], len_nx = 0;
     int64_t off_cur = offsets[clip_cur], off_nx = 0;
+    // the samples of the pair a wave works on next live across items: the last pair of an item requests the first pair
+    // of the NEXT item (its clip, length and offset were requested at the top of this one), so an item does not begin
+    // with an exposed PCM round trip -- which is what lets small batches use small items
+    float xa0[7], xp0[7], xb0[7], xq0[7];
+    bool prefetched = false;
     while (item < n_items) {
-        if (tid == 0 && next_item < n_items) my_ticket = atomicInc(ticket, 0xffffffffu);   // -> the item after the next
         if (next_item < n_items) {
             len_nx = lengths[clip_nx];
             off_nx = offsets[clip_nx];
@@ -653,15 +663,16 @@ __global__ __launch_bounds__(kaldi64::kThreads, kaldi64::kWgPerCu) void kaldi_fb
         const float* __restrict__ x = pcm + (((int64_t)__builtin_amdgcn_readfirstlane((int)(off_cur >> 32)) << 32) |
                                              (uint32_t)__builtin_amdgcn_readfirstlane((int)off_cur));
         const int T = kaldi_num_frames(n_valid, max_frames, t_max);
-        // this wave's frames of the run: 8 per tile
-        const int f_first = run * tiles_per_block * kTileFrames + wave * kFramesPerWave;
-        const int f_run_end = min((run + 1) * tiles_per_block * kTileFrames, T);
+        // the item's frames
+        const int f_first = run * item_frames;
+        const int f_run_end = min(f_first + item_frames, T);
         float* __restrict__ out_clip = out + (size_t)clip * t_max * n_mels;
 
         // samples x[n], x[n - 1] of the pair's two frames for n = lane + 64 m (frame b starts one hop later).  Frame a is
         // a valid frame (fa < T), so all of its samples are inside the clip; frame b of an odd last pair is not: frame a
         // is loaded again in its place (its results are not stored).  No per-sample bounds anywhere.
-        auto load_pair = [&](int fa, float (&xa)[7], float (&xp)[7], float (&xb)[7], float (&xq)[7]) {
+        auto load_pair = [&](const float* __restrict__ x, int T, int n_valid, int fa, float (&xa)[7], float (&xp)[7],
+                             float (&xb)[7], float (&xq)[7]) {
             const int hop_b = (fa + 1 < T) ? kHop : 0;                // wave-uniform
             const int i0 = kHop * fa + lane;
             const float* __restrict__ pa = x + i0;
@@ -689,7 +700,7 @@ __global__ __launch_bounds__(kaldi64::kThreads, kaldi64::kWgPerCu) void kaldi_fb
             xq[6] = in6 ? q6 : 0.0f;
         };
         // frame index of the wave's j-th pair of the run
-        auto pair_frame = [&](int j) { return f_first + (j >> 2) * kTileFrames + 2 * (j & 3); };
+        auto pair_frame = [&](int j) { return f_first + 2 * j; };
         // one frame pair: window stage on (xa, xp, xb, xq), the NEXT pair's samples requested into (na, np, nb, nq)
         auto do_pair = [&](int fa, int fa_next, const float (&xa)[7], const float (&xp)[7], const float (&xb)[7],
                            const float (&xq)[7], float (&na)[7], float (&np)[7], float (&nb)[7], float (&nq)[7]) {
@@ -736,7 +747,23 @@ __global__ __launch_bounds__(kaldi64::kThreads, kaldi64::kWgPerCu) void kaldi_fb
             }
             // unconditional (past the run's end the current, valid, pair is requested again and never used): a
             // conditional block makes the compiler wait for the loads at its end to merge them into the loop registers
-            load_pair(fa_next < f_run_end ? fa_next : fa, na, np, nb, nq);
+            // (the last pair of the item requests the first pair of the next item; without one, itself again)
+            const float* __restrict__ lx = x;
+            int lT = T, lnv = n_valid, lfa = fa_next < f_run_end ? fa_next : fa;
+            if (fa_next >= f_run_end && next_item < n_items) {        // wave-uniform; scalar work only, no loads inside
+                const int nv = __builtin_amdgcn_readfirstlane(len_nx);
+                const int Tn = kaldi_num_frames(nv, max_frames, t_max);
+                const int fn = run_nx * item_frames;
+                if (fn < Tn) {
+                    lx = pcm + (((int64_t)__builtin_amdgcn_readfirstlane((int)(off_nx >> 32)) << 32) |
+                                (uint32_t)__builtin_amdgcn_readfirstlane((int)off_nx));
+                    lT = Tn;
+                    lnv = nv;
+                    lfa = fn;
+                    prefetched = true;
+                }
+            }
+            load_pair(lx, lT, lnv, lfa, na, np, nb, nq);
             dft8d(v);                                                 // over m: Y_l[q]
             wave_lds_sync2();                                         // after the previous pair's mel reads
             {
@@ -827,22 +854,17 @@ __global__ __launch_bounds__(kaldi64::kThreads, kaldi64::kWgPerCu) void kaldi_fb
         // one register set in the source: the next pair's samples are requested after the window stage has consumed
         // this pair's (the compiler lands them in temporaries and copies at the end of the iteration; alternating two
         // explicit sets instead spilled 17 loop-invariant LDS addresses and was slower, 0.231 vs 0.188 ms)
-        float xa0[7], xp0[7], xb0[7], xq0[7];
         int j = 0;
         int fa = pair_frame(0);
-        if (fa < f_run_end) load_pair(fa, xa0, xp0, xb0, xq0);
+        if (fa < f_run_end && !prefetched) load_pair(x, T, n_valid, fa, xa0, xp0, xb0, xq0);
+        prefetched = false;
         while (fa < f_run_end) {
             const int fa_next = pair_frame(j + 1);
             do_pair(fa, fa_next, xa0, xp0, xb0, xq0, xa0, xp0, xb0, xq0);
             fa = fa_next;
             ++j;
         }
-        // hand-over of the next item through one of two alternating LDS slots (a slot is rewritten only after the
-        // barrier of the following item, which every thread reaches after this read)
-        if (tid == 0) s_next[iter & 1u] = next_item < n_items ? my_ticket + 2 * gridDim.x : (unsigned)n_items;
-        __syncthreads();
-        const int after_next = (int)min(s_next[iter & 1u], (unsigned)n_items);
-        ++iter;
+        const int after_next = min(next_item + n_workers, n_items);
         item = next_item;
         clip_cur = clip_nx;
         run_cur = run_nx;
@@ -1375,7 +1397,24 @@ extern "C" int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, 
     (void)hipGetLastError();
     if (hip_failed(hipMemsetAsync(stats, 0, need, stream), "hipMemsetAsync(cmvn stats)")) return STTFE_E_LAUNCH;
     const auto* tab = reinterpret_cast<const KaldiTablesHeader*>(dev_tables);
-    const int n_tiles = (t_max + kaldi::kTileFrames - 1) / kaldi::kTileFrames;
+    // The float64 kernel's items belong to waves and are 1 ... 8 frame pairs long: with equal-sized items the kernel ends
+    // when the waves with one item more than the others do, so a batch that would give a wave only a few long items is
+    // cut finer, while an item switch costs ~0.6 us -- about five items per wave measured best (config 2's clip lengths,
+    // 64 / 256 / 1024 clips: 1-2 / 4 / 8-16 pairs, profiles/r3_kaldi_items.txt).  STTFE_KALDI_ITEM_PAIRS: tuning knob.
+    auto item_frames64 = [&](int clips) {
+        static const int ip_env = [] {
+            const char* e = getenv("STTFE_KALDI_ITEM_PAIRS");
+            const int v = e ? atoi(e) : 0;
+            return (v >= 1 && v <= 64) ? v : 0;
+        }();
+        const long waves64 = (long)kaldi64::kWaves * kaldi64::kWgPerCu * current_device_cus();
+        const long pairs = (long)clips * ((t_max + 1) / 2) / 2;            // half of the padded batch: the lengths are on the device
+        long per = pairs / (5 * waves64);
+        per = per < 1 ? 1 : (per > 8 ? 8 : per);
+        return 2 * (ip_env ? ip_env : (int)per);
+    };
+    const int tile_frames = kaldi::kTileFrames;
+    const int n_tiles = (t_max + tile_frames - 1) / tile_frames;
     const int resident = 2 * current_device_cus();
     // persistent workgroups, two per CU; short runs keep ragged batches balanced: about eight items per workgroup,
     // taking half of batch x n_tiles as the batch's tiles (the lengths are on the device), within [2, 8] -- 2 tiles
@@ -1388,13 +1427,10 @@ extern "C" int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, 
     }();
     int tiles_per_block = tpb_env;
     if (tiles_per_block == 0) {
-        // the float64 kernel is wave-local (no barrier per tile) and runs three workgroups per CU: single-tile items
-        // balance config 2 best there (1: 0.173, 2: 0.183, 3: 0.182, 4: 0.199 ms; float32 kernel 0.110 / 0.106 / 0.112 / 0.116)
-        const bool f64 = flags & STTFE_KALDI_F64;
-        const long wgs = f64 ? (long)kaldi64::kWgPerCu * current_device_cus() : resident;
-        const long est = (long)batch * n_tiles / 2 / (8L * wgs);
-        const long lo = f64 ? 1 : 2;
-        tiles_per_block = est < lo ? (int)lo : (est > 8 ? 8 : (int)est);
+        // (float32 kernel: 1 / 2 / 3 / 4 tiles per item 0.110 / 0.106 / 0.112 / 0.116 ms on config 2; the float64 kernel's
+        // items are sized above and are one "tile" each)
+        const long est = (long)batch * n_tiles / 2 / (8L * resident);
+        tiles_per_block = est < 2 ? 2 : (est > 8 ? 8 : (int)est);
     }
     const int n_runs = (n_tiles + tiles_per_block - 1) / tiles_per_block;
     if ((long)n_runs * batch > 0x3fffffffL) return STTFE_E_UNSUPPORTED;
@@ -1404,10 +1440,18 @@ extern "C" int sttfe_kaldi_fbank_cmvn(const float* pcm, const int64_t* offsets, 
     {
         ScopedTiming t(kTimeKaldiFbank, stream);
         if (flags & STTFE_KALDI_F64) {
+            // at most kKaldiPlanClips clips per launch: the kernel strides through the COMPACTED item space
             const int res64 = kaldi64::kWgPerCu * current_device_cus();
-            const int grid64 = n_items < res64 ? n_items : res64;
-            hipLaunchKernelGGL(kaldi_fbank64_kernel, dim3(grid64), dim3(kaldi64::kThreads), 0, stream, pcm, offsets,
-                               lengths, n_mels, t_max, max_frames, tab, out, tiles_per_block, n_runs, n_items, ticket, batch);
+            for (int c0 = 0; c0 < batch; c0 += kKaldiPlanClips) {
+                const int bc = batch - c0 < kKaldiPlanClips ? batch - c0 : kKaldiPlanClips;
+                const int frames = item_frames64(bc);
+                const int runs64 = (t_max + frames - 1) / frames;
+                const int items64 = runs64 * bc;
+                const int want64 = (items64 + kaldi64::kWaves - 1) / kaldi64::kWaves;      // items belong to waves
+                hipLaunchKernelGGL(kaldi_fbank64_kernel, dim3(want64 < res64 ? want64 : res64), dim3(kaldi64::kThreads), 0,
+                                   stream, pcm, offsets + c0, lengths + c0, n_mels, t_max, max_frames, tab,
+                                   out + (size_t)c0 * t_max * n_mels, runs64, items64, bc, frames);
+            }
         } else {
             hipLaunchKernelGGL(kaldi_fbank_kernel, dim3(grid), dim3(kaldi::kThreads), 0, stream, pcm, offsets,
                                lengths, n_mels, t_max, max_frames, tab, out, stats, tiles_per_block, n_runs, n_items, ticket, batch);
