@@ -272,6 +272,47 @@ def test_fused_cmvn_chain_every_block_remainder(fe, monkeypatch):
         assert not a[1:].isnan().any()                                # (one frame: std 0, NaN as in HF)
 
 
+def test_float64_item_sizes_and_chunked_launches_give_the_same_bits(fe):
+    """The float64 kernel's work items belong to waves and are 1 ... 8 frame pairs long (sized by the host from the
+    batch, STTFE_KALDI_ITEM_PAIRS overrides; read once per process), and batches of more than 1024 clips go as several
+    launches: every item size must give the bits of the automatic one (child processes print a digest), and a
+    1100-clip batch the bits of its two parts extracted separately."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    lens = [48000, 123457, 16000, 400, 399, 0, 559, 560, 561, 720, 33333, 159999, 160000, 80001, 879, 880, 881]
+    clips = synth_batch(91, lens)
+    ref = fe(clips, sampling_rate=16000).input_features.cpu().numpy()
+    digest = hashlib.sha256(np.nan_to_num(ref, nan=12345.0).tobytes()).hexdigest()
+    code = r"""
+import hashlib, numpy as np
+from speech_to_text_amd.processors import HipSpeech2TextFeatureExtractor
+from speech_to_text_amd.synth import synth_batch
+fe = HipSpeech2TextFeatureExtractor(device="cuda:0")
+lens = %r
+out = fe(synth_batch(91, lens), sampling_rate=16000).input_features.cpu().numpy()
+print("digest", hashlib.sha256(np.nan_to_num(out, nan=12345.0).tobytes()).hexdigest())
+""" % (lens,)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for pairs in ("1", "3", "8", "64"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, STTFE_KALDI_ITEM_PAIRS=pairs),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and ("digest " + digest) in r.stdout, (pairs, r.stdout[-500:], r.stderr[-2000:])
+    # more clips than one launch takes
+    from speech_to_text_amd.processors import pack_clips
+    rng = np.random.default_rng(92)
+    many = synth_batch(92, rng.integers(400, 4000, size=1100).tolist())
+    pcm, off, ln = pack_clips(list(many), torch.device("cuda:0"))
+    t_max = max(fe.num_frames(len(c)) for c in many)
+    whole, _ = fe.extract(pcm, off, ln, t_max)
+    a, _ = fe.extract(pcm, off[:1024].contiguous(), ln[:1024].contiguous(), t_max)
+    b, _ = fe.extract(pcm, off[1024:].contiguous(), ln[1024:].contiguous(), t_max)
+    parts = torch.cat([a, b]).cpu()
+    whole = whole.cpu()
+    assert bool(((whole == parts) | (whole.isnan() & parts.isnan())).all())
+
+
 @pytest.mark.parametrize("mode", ["float64", "float32"])
 @pytest.mark.parametrize("tag,means,varis", [("mean_only", True, False), ("var_only", False, True)])
 def test_cmvn_means_or_vars_alone_match_hf_goldens(mode, tag, means, varis, monkeypatch):
