@@ -599,11 +599,13 @@ def main():
         # Calls that qualify for the 12-wave kernel of uniform batches (80 bins, no masks, no scale) launch both STFT kernels
         # and the lengths on the device decide which one works; the other returns at once.  The one that did the work is the
         # dominant kernel of the line, the empty launch is listed beside it.
+        # (batches of up to 3072 such clips are computed by the 12-wave kernel alone, uniform or ragged: one STFT launch)
         t12, n12 = query("whisper_stft_mel12")
         t1, n1 = query("whisper_stft_mel")
         if n12 > 0 and t12 / n12 > t1 / max(n1, 1):
             kernel, kname = "whisper_stft_mel12", "whisper_stft_mel12_kernel"
-            others["whisper_stft_mel (returns at once: the batch is uniform)"] = (t1, n1)
+            if n1 > 0:
+                others["whisper_stft_mel (returns at once: the batch is uniform)"] = (t1, n1)
         elif n12 > 0:
             others["whisper_stft_mel12 (returns at once: the batch is not uniform)"] = (t12, n12)
     tot_ms, timed_launches = query(kernel)

@@ -1331,13 +1331,20 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
     const long most_items = (long)batch * ((n_tiles + 2) / 3);      // fewer workgroups than that cannot all find work
     const int grid = most_items < resident ? (int)most_items : resident;
     const auto* tab = reinterpret_cast<const WhisperTablesHeader*>(dev_tables);
-    // Uniform batches of the 80- and 128-bin extractors (HF mode, no masks, no per-clip scale) are computed by
-    // whisper_stft_mel12_kernel (whisper_logmel12.inc).  Whether a batch is uniform is only known on the device, so such a
-    // call launches BOTH kernels and each returns at once if the batch is the other's (the same predicate on the same
-    // lengths: whisper_batch_is_uniform); a ragged batch pays one empty launch (~3 us) for it.
+    // Calls of the 80- and 128-bin extractors in HF mode without a per-clip scale (with or without SpecAugment masks) are computed by
+    // whisper_stft_mel12_kernel (whisper_logmel12.inc).  Batches of up to wh12::kPlanClips clips: by that kernel ALONE,
+    // uniform or ragged (it builds the ragged batch's item plan in its LDS) -- one STFT launch.  Larger batches: only if
+    // uniform, which is known on the device alone, so such a call launches BOTH kernels and each returns at once if the
+    // batch is the other's (the same predicate on the same lengths: whisper_batch_is_uniform).
+    // STTFE_WH12_RAGGED=0: ragged batches of any size stay with whisper_stft_mel_kernel (A/B and test knob).
+    static const bool ragged12 = [] {
+        const char* e = getenv("STTFE_WH12_RAGGED");
+        return !(e && atoi(e) == 0);
+    }();
     const bool try_uniform = whisper_uniform_kernel_enabled() && (n_mels == 80 || n_mels == 128) && mode == wh::kModeHF &&
-                             (!mask_tbl || n_masks == 0) && !clip_scale && batch <= 16384 && whisper_uniform_kernel_ready();
-    const bool sure_uniform = try_uniform && batch == 1;      // one clip is a uniform batch whatever its length: no second launch
+                             !clip_scale && batch <= 16384 && whisper_uniform_kernel_ready();
+    // (one clip is a uniform batch whatever its length)
+    const bool sure_uniform = try_uniform && (batch == 1 || (ragged12 && batch <= wh12::kPlanClips));
     if (try_uniform) {
         ScopedTiming t(kTimeWhisperStftMel12, stream);
         const int cus = current_device_cus();
@@ -1346,11 +1353,11 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
         if (n_mels == 80)
             hipLaunchKernelGGL(whisper_stft_mel12_kernel<80>, dim3(grid12), dim3(wh12::kThreads),
                                (size_t)wh12::kLdsFloats * sizeof(float), stream, pcm, offsets, lengths, n_frames, tab, out, keys,
-                               batch, tiles_per_block, sure_uniform ? 0 : 1);
+                               batch, tiles_per_block, sure_uniform ? 0 : 1, mask_tbl, n_masks);
         else
             hipLaunchKernelGGL(whisper_stft_mel12_kernel<128>, dim3(grid12), dim3(wh12::kThreads),
                                (size_t)wh12::kLdsFloats * sizeof(float), stream, pcm, offsets, lengths, n_frames, tab, out, keys,
-                               batch, tiles_per_block, sure_uniform ? 0 : 1);
+                               batch, tiles_per_block, sure_uniform ? 0 : 1, mask_tbl, n_masks);
     }
     if (!sure_uniform) {
         ScopedTiming t(kTimeWhisperStftMel, stream);

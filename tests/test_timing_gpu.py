@@ -32,11 +32,11 @@ def test_sampled_event_timing_counts_and_durations():
             for _ in range(launches):
                 fe(clips, sampling_rate=16000)
             torch.cuda.synchronize()
-            ms, timed, seen = query(L, b"whisper_stft_mel")
+            ms, timed, seen = query(L, b"whisper_stft_mel12")       # 80 bins, HF mode, <= 3072 clips: the 12-wave kernel alone
             assert seen == launches and timed == (launches + stride - 1) // stride
             assert 0.0 < ms / timed < 50.0                          # a few microseconds to milliseconds per launch
             assert query(L, b"whisper_clamp_fill")[1:] == (timed, seen)
-            assert query(L, b"whisper_stft_mel12")[1:] == (timed, seen)    # 80 bins, no masks: both STFT kernels are launched
+            assert query(L, b"whisper_stft_mel")[1:] == (0, 0)      # (the general kernel is not launched for such a call)
             assert query(L, b"kaldi_fbank")[1:] == (0, 0)
         assert L.sttfe_timing_set_stride(0) == -1
         n = ctypes.c_int()
@@ -46,4 +46,4 @@ def test_sampled_event_timing_counts_and_durations():
         L.sttfe_timing_enable(0)
     for _ in range(2):
         fe(clips, sampling_rate=16000)                              # disabled: nothing is recorded
-    assert query(L, b"whisper_stft_mel")[1] == 0
+    assert query(L, b"whisper_stft_mel12")[1] == 0

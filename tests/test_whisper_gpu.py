@@ -234,6 +234,52 @@ def test_uniform_batches_on_the_12_wave_kernel_are_bit_identical(n_mels, fe80, f
     assert L.sttfe_set_whisper_uniform_kernel(2) == -1 and L.sttfe_set_whisper_uniform_kernel(-1) == -1
 
 
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_ragged_and_masked_batches_on_the_12_wave_kernel_are_bit_identical(n_mels, fe80, fe128):
+    """Batches of up to 3072 clips of the 80- and 128-bin extractors are computed by whisper_stft_mel12_kernel alone --
+    ragged ones through an item plan it builds in LDS (clip-major runs, static striding), SpecAugment masks in its mel
+    waves.  Same bits as the general kernel (knob off): ragged batches with every awkward length mid-batch, with up to 16
+    masks per clip on both axes (some outside the clip, some empty), compact n_frames, and a batch of 700 short clips
+    (several items per workgroup, clips without a second tile)."""
+    from speech_to_text_amd import _lib
+    from speech_to_text_amd.processors import pack_clips
+    L = _lib.lib()
+    fe = fe80 if n_mels == 80 else fe128
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(77)
+    awkward = [0, 1, 199, 200, 201, 7479, 7480, 7481, 7679, 7680, 7681, 23039, 23040, 23041, 464000, 464001, 479840, 479841,
+               479999, 480000, 240000, 7]
+    cases = [(awkward + rng.integers(1, 480001, 40).tolist(), 3000, 0),
+             (awkward + rng.integers(1, 480001, 40).tolist(), 3000, 16),
+             (rng.integers(16000, 160001, 96).tolist(), 3000, 4),
+             (rng.integers(16000, 160001, 33).tolist(), 1000, 3),
+             (rng.integers(100, 9000, 700).tolist(), 3000, 2)]
+    try:
+        for lens, n_frames, k in cases:
+            clips = synth_batch(41 + k, lens)
+            pcm, off, ln = pack_clips(list(clips), dev, max(lens))
+            tbl = None
+            if k:
+                t = np.zeros((len(lens), k, 3), dtype=np.int32)
+                t[:, :, 0] = rng.integers(0, 2, size=(len(lens), k))                        # axis: 1 = time, 0 = mel
+                start = np.where(t[:, :, 0] == 1, rng.integers(0, n_frames, size=(len(lens), k)),
+                                 rng.integers(0, n_mels, size=(len(lens), k)))
+                t[:, :, 1] = start
+                t[:, :, 2] = start + rng.integers(0, 60, size=(len(lens), k))               # (may be empty or overhang)
+                tbl = torch.tensor(t, device=dev)
+            res = []
+            for on in (0, 1):
+                assert L.sttfe_set_whisper_uniform_kernel(on) == 0
+                out = torch.full((len(lens), n_mels, n_frames), -3.0, dtype=torch.float32, device=dev)
+                fe.extract(pcm, off, ln, out=out, mask_table=tbl)
+                torch.cuda.synchronize()
+                res.append(out)
+            assert torch.equal(res[0], res[1]), (len(lens), n_frames, k)
+            assert torch.isfinite(res[1]).all()
+    finally:
+        L.sttfe_set_whisper_uniform_kernel(1)
+
+
 def test_uniform_kernel_handover_over_many_tiles(fe80):
     """The 12-wave kernel hands its power panel from the transform waves to the mel waves through two LDS counters (no
     barrier): 300 full-length clips = 19 k tiles per launch, repeated launches, every run length -- each result bit for
