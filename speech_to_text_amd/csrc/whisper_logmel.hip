@@ -1331,7 +1331,7 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
     const long most_items = (long)batch * ((n_tiles + 2) / 3);      // fewer workgroups than that cannot all find work
     const int grid = most_items < resident ? (int)most_items : resident;
     const auto* tab = reinterpret_cast<const WhisperTablesHeader*>(dev_tables);
-    // Calls of the 80- and 128-bin extractors in HF mode without a per-clip scale (with or without SpecAugment masks) are computed by
+    // Calls of the 80- and 128-bin extractors in HF mode (with or without SpecAugment masks or a per-clip scale) are computed by
     // whisper_stft_mel12_kernel (whisper_logmel12.inc).  Batches of up to wh12::kPlanClips clips: by that kernel ALONE,
     // uniform or ragged (it builds the ragged batch's item plan in its LDS) -- one STFT launch.  Larger batches: only if
     // uniform, which is known on the device alone, so such a call launches BOTH kernels and each returns at once if the
@@ -1342,7 +1342,7 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
         return !(e && atoi(e) == 0);
     }();
     const bool try_uniform = whisper_uniform_kernel_enabled() && (n_mels == 80 || n_mels == 128) && mode == wh::kModeHF &&
-                             !clip_scale && batch <= 16384 && whisper_uniform_kernel_ready();
+                             batch <= 16384 && whisper_uniform_kernel_ready();
     // (one clip is a uniform batch whatever its length)
     const bool sure_uniform = try_uniform && (batch == 1 || (ragged12 && batch <= wh12::kPlanClips));
     if (try_uniform) {
@@ -1353,11 +1353,11 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
         if (n_mels == 80)
             hipLaunchKernelGGL(whisper_stft_mel12_kernel<80>, dim3(grid12), dim3(wh12::kThreads),
                                (size_t)wh12::kLdsFloats * sizeof(float), stream, pcm, offsets, lengths, n_frames, tab, out, keys,
-                               batch, tiles_per_block, sure_uniform ? 0 : 1, mask_tbl, n_masks);
+                               batch, tiles_per_block, sure_uniform ? 0 : 1, mask_tbl, n_masks, clip_scale);
         else
             hipLaunchKernelGGL(whisper_stft_mel12_kernel<128>, dim3(grid12), dim3(wh12::kThreads),
                                (size_t)wh12::kLdsFloats * sizeof(float), stream, pcm, offsets, lengths, n_frames, tab, out, keys,
-                               batch, tiles_per_block, sure_uniform ? 0 : 1, mask_tbl, n_masks);
+                               batch, tiles_per_block, sure_uniform ? 0 : 1, mask_tbl, n_masks, clip_scale);
     }
     if (!sure_uniform) {
         ScopedTiming t(kTimeWhisperStftMel, stream);

@@ -267,11 +267,13 @@ def test_ragged_and_masked_batches_on_the_12_wave_kernel_are_bit_identical(n_mel
                 t[:, :, 1] = start
                 t[:, :, 2] = start + rng.integers(0, 60, size=(len(lens), k))               # (may be empty or overhang)
                 tbl = torch.tensor(t, device=dev)
+            # (k == 4: also with a per-clip amplitude scale, sttfe_whisper_logmel_scaled)
+            scale = torch.tensor(rng.uniform(0.5, 300.0, len(lens)).astype(np.float32), device=dev) if k == 4 else None
             res = []
             for on in (0, 1):
                 assert L.sttfe_set_whisper_uniform_kernel(on) == 0
                 out = torch.full((len(lens), n_mels, n_frames), -3.0, dtype=torch.float32, device=dev)
-                fe.extract(pcm, off, ln, out=out, mask_table=tbl)
+                fe.extract(pcm, off, ln, out=out, mask_table=tbl, clip_scale=scale)
                 torch.cuda.synchronize()
                 res.append(out)
             assert torch.equal(res[0], res[1]), (len(lens), n_frames, k)

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd, prefix = sys.argv[1], sys.argv[2]
 DOMINANT = {"whisper80": "whisper_stft_mel12_kernel", "whisper128_aug": "whisper_stft_mel12_kernel",
             "resample_whisper": "whisper_stft_mel12_kernel", "resample_whisper_s16": "whisper_stft_mel12_kernel",
-            "resample_whisper_fused": "whisper_stft_mel_kernel",      # (per-clip scale: the general kernel)
+            "resample_whisper_fused": "whisper_stft_mel12_kernel",
             "s2t": "kaldi_fbank64_kernel", "s2t_f32": "kaldi_fbank_kernel"}
 CLIPS = {"whisper80": 1024, "whisper128_aug": 1024, "resample_whisper": 512, "resample_whisper_s16": 512,
          "resample_whisper_fused": 512, "s2t": 256, "s2t_f32": 256}
