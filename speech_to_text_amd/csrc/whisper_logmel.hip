@@ -31,9 +31,11 @@
 //     workspace with one atomic per wave.
 //   Tiles that lie entirely in the padding are left to kernel 2 (they are constant).
 //   Three modes (kMode*): HF semantics, and the two of the reference's TorchWhisperFeatureExtractor.
-// Kernel 1', uniform batches of the 80- and 128-bin extractors (stft_mel12, whisper_logmel12.inc): one 768-thread workgroup per CU, eight
-//   transform waves + four mel waves handing the power panel over through LDS counters; same arithmetic, same bits.  Calls
-//   that qualify (HF mode, no masks, no scale) launch both kernels and the lengths on the device decide which one works.
+// Kernel 1', the 80- and 128-bin extractors in HF mode (stft_mel12, whisper_logmel12.inc): one 768-thread workgroup per CU, eight
+//   transform waves + four mel waves handing the power panel over through LDS counters; same arithmetic, same bits.  It
+//   computes batches of up to 3072 clips alone (uniform or ragged, masks, per-clip scale); larger batches launch both
+//   kernels and the lengths on the device decide which one works.  This file's kernel 1 keeps the torch modes, other bin
+//   counts and ragged batches beyond 3072 clips.
 // Kernel 2 (clamp_fill): 16-32 workgroups per clip, each owning 4-5 interleaved mel rows.  The zero-padding region is filled
 //   with the final constant (write only); of the computed tiles only those whose recorded minimum is below
 //   max - 8 are re-read and clamped to (max - 8 + 4) / 4 (everything else is already final).
