@@ -293,17 +293,19 @@ int sttfe_pitch_shift_plan(const int32_t* lengths, const int32_t* n_steps, int b
 int sttfe_pitch_shift(float* pcm, const int64_t* offsets, const int32_t* lengths, int batch, const int64_t* layout,
                       const int64_t* dev_layout, int mode, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Consecutive 48-frame tiles per work item of the STFT kernel (0 = automatic, the default: the kernel derives it
- * from the clip lengths it finds on the device -- a third of the clip for uniform batches, about eight items
- * per workgroup otherwise, within [3, 21]).  Tuning knob, no counterpart in the reference. */
+/* Consecutive 48-frame tiles per work item of the STFT kernels (0 = automatic, the default: the kernel derives it
+ * from the clip lengths it finds on the device -- general kernel: a third of the clip for uniform batches, about eight
+ * items per workgroup otherwise, within [3, 21]; 12-wave kernel: about eight (uniform) or sixteen (ragged) items per
+ * workgroup, within [1, 21]).  Tuning knob, no counterpart in the reference. */
 int sttfe_set_whisper_tiles_per_block(int tiles);
 
-/* Uniform batches of the 80- and 128-bin extractors (every clip within a 48-frame tile of the longest one: 30 s chunks of
- * long-form audio, padded corpora; HF mode, no masks, no per-clip scale) are computed by a second STFT kernel built for
- * them (one 12-wave workgroup per CU with transform and mel waves, csrc/whisper_logmel12.inc; bit-identical features).
- * on = 1 (default): such calls launch both STFT kernels and the lengths on the device decide which of them works;
- * on = 0: every call takes the general kernel.  Also env STTFE_WH_UNIFORM_KERNEL=0/1 (the API call wins).
- * Tuning / A-B knob, no counterpart in the reference. */
+/* Calls of the 80- and 128-bin extractors in HF mode (sttfe_whisper_logmel, _scaled, _static; with or without masks) are
+ * computed by a second STFT kernel (one 12-wave workgroup per CU with transform and mel waves,
+ * csrc/whisper_logmel12.inc; bit-identical features).  on = 1 (default): batches of up to 3072 clips take that kernel
+ * alone, uniform or ragged; larger batches launch both STFT kernels and the lengths on the device decide which of them
+ * works (the 12-wave kernel if every clip ends within a 48-frame tile of the longest one).  on = 0: every call takes the
+ * general kernel.  Also env STTFE_WH_UNIFORM_KERNEL=0/1 (the API call wins); env STTFE_WH12_RAGGED=0 keeps ragged
+ * batches of any size on the general kernel.  Tuning / A-B knobs, no counterpart in the reference. */
 int sttfe_set_whisper_uniform_kernel(int on);
 
 /* ------------------------------------------------------------- measurement support -----------
