@@ -68,3 +68,32 @@ def test_bulk_uniform_draws_equal_successive_single_draws():
         bulk = torch.rand(n)
         after_bulk = torch.rand(1)
         assert torch.equal(single, bulk) and torch.equal(after_single, after_bulk)
+
+
+def test_batched_mask_table_equals_per_clip_draws():
+    """``mask_table`` draws the whole batch at once (the gates from Python's generator, every passing clip's uniform
+    numbers from ONE ``torch.rand`` call): the table and both generators' states afterwards are those of per-clip
+    ``draw_clip`` calls in batch order -- for the default configuration, with an axis switched off, without frequency
+    masks, with every clip passing and with nothing to draw."""
+    import random
+
+    import torch
+
+    from speech_to_text_amd.augment import SpecAugmentSampler
+    shapes = [(80 if i % 3 else 128, 100 + 7 * i) for i in range(300)]
+    for kw in ({}, {"time_mask_max_size": 0}, {"num_freq_masks": 0}, {"spec_augment_probability": 1.0},
+               {"freq_mask_max_size": 0, "time_mask_max_size": 0}, {"spec_augment": False}):
+        s = SpecAugmentSampler(None, **kw)
+        random.seed(5)
+        torch.manual_seed(5)
+        got = s.mask_table(shapes)
+        after_got = (random.random(), torch.rand(1).item())
+        random.seed(5)
+        torch.manual_seed(5)
+        exp = torch.zeros((len(shapes), max(s.masks_per_clip, 1), 3), dtype=torch.int32)
+        for b, (n_freq, n_time) in enumerate(shapes):
+            for i, (axis, start, end) in enumerate(s.draw_clip(n_freq, n_time)):
+                exp[b, i, 0], exp[b, i, 1], exp[b, i, 2] = axis, start, end
+        after_exp = (random.random(), torch.rand(1).item())
+        assert torch.equal(got, exp), kw
+        assert after_got == after_exp, kw
