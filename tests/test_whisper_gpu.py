@@ -239,8 +239,8 @@ def test_ragged_and_masked_batches_on_the_12_wave_kernel_are_bit_identical(n_mel
     """Batches of up to 3072 clips of the 80- and 128-bin extractors are computed by whisper_stft_mel12_kernel alone --
     ragged ones through an item plan it builds in LDS (clip-major runs, static striding), SpecAugment masks in its mel
     waves.  Same bits as the general kernel (knob off): ragged batches with every awkward length mid-batch, with up to 16
-    masks per clip on both axes (some outside the clip, some empty), compact n_frames, and a batch of 700 short clips
-    (several items per workgroup, clips without a second tile)."""
+    masks per clip on both axes (some outside the clip, some empty), compact n_frames, a batch of 700 short clips
+    (several items per workgroup, clips without a second tile) and batches of 3100 clips, which launch both kernels."""
     from speech_to_text_amd import _lib
     from speech_to_text_amd.processors import pack_clips
     L = _lib.lib()
@@ -253,7 +253,9 @@ def test_ragged_and_masked_batches_on_the_12_wave_kernel_are_bit_identical(n_mel
              (awkward + rng.integers(1, 480001, 40).tolist(), 3000, 16),
              (rng.integers(16000, 160001, 96).tolist(), 3000, 4),
              (rng.integers(16000, 160001, 33).tolist(), 1000, 3),
-             (rng.integers(100, 9000, 700).tolist(), 3000, 2)]
+             (rng.integers(100, 9000, 700).tolist(), 3000, 2),
+             (rng.integers(100, 3000, 3100).tolist(), 52, 0),       # more clips than the item plan holds: both kernels launched
+             ([2500] * 3100, 52, 1)]                                # the same, uniform
     try:
         for lens, n_frames, k in cases:
             clips = synth_batch(41 + k, lens)
