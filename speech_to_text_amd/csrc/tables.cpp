@@ -9,6 +9,7 @@
 
 #include "../../include/sttfe.h"
 #include "tables.h"
+#include "whisper_mel_bands.h"
 
 namespace sttfe {
 
@@ -164,6 +165,23 @@ extern "C" int sttfe_whisper_mel_bank(int n_mels, float* host_dense) {
     return STTFE_OK;
 }
 
+// True when the generated per-mel band extents (whisper_mel_bands.h) are exactly the bank's: first / last non-zero bin of
+// every mel row.  The 12-wave kernel's band-sparse projection skips every product outside them.
+template <int NM>
+static bool bands_match(const std::vector<float>& dense) {
+    for (int m = 0; m < NM; ++m)
+        for (int k = 0; k < 201; ++k) {
+            const bool inside = k >= wh::MelBand<NM>::lo[m] && k <= wh::MelBand<NM>::hi[m];
+            const bool edge = k == wh::MelBand<NM>::lo[m] || k == wh::MelBand<NM>::hi[m];
+            const float w = dense[(size_t)m * 201 + k];
+            if ((!inside && w != 0.0f) || (edge && w == 0.0f)) return false;
+        }
+    return true;
+}
+static bool whisper_bands_match(const std::vector<float>& dense, int n_mels) {
+    return n_mels == 80 ? bands_match<80>(dense) : (n_mels == 128 ? bands_match<128>(dense) : false);
+}
+
 static int whisper_tables(int n_mels, std::vector<unsigned char>& blob) {
     if (n_mels < 1 || n_mels > 128) return STTFE_E_INVALID_ARG;
     std::vector<float> dense, afrag;
@@ -176,6 +194,7 @@ static int whisper_tables(int n_mels, std::vector<unsigned char>& blob) {
     h.magic = kWhisperMagic;
     h.n_mels = n_mels;
     h.afrag_floats = (int32_t)afrag.size();
+    h.reserved = whisper_bands_match(dense, n_mels) ? 1 : 0;   // bit 0: whisper_mel_bands.h describes this bank (band-sparse projection allowed)
     for (int i = 0; i < 400; ++i) h.window[i] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * i / 400.0));
     for (int k1 = 0; k1 < 20; ++k1)
         for (int j = 0; j < 20; ++j) {

@@ -51,6 +51,7 @@
 #include "fft_core.h"
 #include "fft_pk.h"
 #include "tables.h"
+#include "whisper_mel_bands.h"
 #include "timing.h"
 
 namespace sttfe {
@@ -1343,6 +1344,12 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
         const char* e = getenv("STTFE_WH12_RAGGED");
         return !(e && atoi(e) == 0);
     }();
+    // STTFE_WH12_MFMA=1: the mel waves project with MFMAs (mel_unit12) instead of the band-sparse packed-VALU form (A/B knob;
+    // the same bits either way)
+    static const int mfma_flag = [] {
+        const char* e = getenv("STTFE_WH12_MFMA");
+        return (e && atoi(e) != 0) ? 2 : 0;
+    }();
     const bool try_uniform = whisper_uniform_kernel_enabled() && (n_mels == 80 || n_mels == 128) && mode == wh::kModeHF &&
                              batch <= 16384 && whisper_uniform_kernel_ready();
     // (one clip is a uniform batch whatever its length)
@@ -1355,11 +1362,11 @@ static int whisper_logmel_impl(const float* pcm, const int64_t* offsets, const i
         if (n_mels == 80)
             hipLaunchKernelGGL(whisper_stft_mel12_kernel<80>, dim3(grid12), dim3(wh12::kThreads),
                                (size_t)wh12::kLdsFloats * sizeof(float), stream, pcm, offsets, lengths, n_frames, tab, out, keys,
-                               batch, tiles_per_block, sure_uniform ? 0 : 1, mask_tbl, n_masks, clip_scale);
+                               batch, tiles_per_block, (sure_uniform ? 0 : 1) | mfma_flag, mask_tbl, n_masks, clip_scale);
         else
             hipLaunchKernelGGL(whisper_stft_mel12_kernel<128>, dim3(grid12), dim3(wh12::kThreads),
                                (size_t)wh12::kLdsFloats * sizeof(float), stream, pcm, offsets, lengths, n_frames, tab, out, keys,
-                               batch, tiles_per_block, sure_uniform ? 0 : 1, mask_tbl, n_masks, clip_scale);
+                               batch, tiles_per_block, (sure_uniform ? 0 : 1) | mfma_flag, mask_tbl, n_masks, clip_scale);
     }
     if (!sure_uniform) {
         ScopedTiming t(kTimeWhisperStftMel, stream);
