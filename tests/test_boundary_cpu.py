@@ -64,6 +64,31 @@ def test_whisper_mel_bank_matches_oracle(n_mels):
     assert np.abs(dense.T - ref).max() <= 1e-9
 
 
+def test_generated_mel_bands_describe_the_bank():
+    """csrc/whisper_mel_bands.h (tools/gen_mel_bands.py) holds the first / last non-zero bin of every mel row: the 12-wave
+    kernel's band-sparse projection skips every product outside them.  The tables builder checks the header against the bank
+    it builds and says so in the blob's header (word 3, bit 0): set for the two Whisper extractors, clear for any other bin
+    count (those take the MFMA projection).  The header itself is what the generator would write today."""
+    import struct
+    L = _lib.lib()
+    for n_mels, want in ((80, 1), (128, 1), (40, 0), (64, 0)):
+        n = ctypes.c_size_t()
+        _lib.check(L.sttfe_whisper_tables_bytes(n_mels, ctypes.byref(n)))
+        blob = ctypes.create_string_buffer(n.value)
+        _lib.check(L.sttfe_whisper_tables_build(n_mels, blob, n))
+        magic, nm, afrag_floats, flags = struct.unpack("Iiii", blob.raw[:16])
+        assert nm == n_mels and (flags & 1) == want
+    text = open(os.path.join(ROOT, "speech_to_text_amd", "csrc", "whisper_mel_bands.h")).read()
+    for n_mels in (80, 128):
+        dense = np.empty((n_mels, 201), dtype=np.float32)
+        _lib.check(L.sttfe_whisper_mel_bank(n_mels, dense.ctypes.data_as(ctypes.c_void_p)))
+        lo = [int(np.nonzero(r)[0][0]) for r in dense]
+        hi = [int(np.nonzero(r)[0][-1]) for r in dense]
+        assert f"lo[{n_mels}] = {{{', '.join(map(str, lo))}}};" in text
+        assert f"hi[{n_mels}] = {{{', '.join(map(str, hi))}}};" in text
+        assert all(int(np.count_nonzero(r)) == h - l + 1 for r, l, h in zip(dense, lo, hi))
+
+
 def test_kaldi_mel_bank_matches_oracle():
     from oracle.kaldi import mel_filter_bank_kaldi
     dense = np.empty((80, 257), dtype=np.float32)

@@ -284,6 +284,43 @@ def test_ragged_and_masked_batches_on_the_12_wave_kernel_are_bit_identical(n_mel
         L.sttfe_set_whisper_uniform_kernel(1)
 
 
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_band_sparse_projection_equals_the_mfma_projection_on_amplitude_extremes(n_mels, fe80, fe128):
+    """The 12-wave kernel's mel waves project band-sparse on the vector ALU, in the MFMA's own accumulation order; the
+    general kernel projects with MFMAs.  Same bits on signals scaled from 1e-20 (every product a denormal or zero) to 1e15
+    (power up to 1e37), on silence, an impulse and DC, with and without the per-clip scale that moves the floor with the
+    signal.  (From |x| ~ 1e17 on the POWER overflows float32 and the two differ: an Inf reaches every mel of its 16-mel
+    tile through the MFMAs' zero weights, only the mels of its band here -- tools/ubench/wh12_extremes.py,
+    profiles/r3_wh12_extremes.txt.)"""
+    from speech_to_text_amd import _lib
+    from speech_to_text_amd.processors import pack_clips
+    L = _lib.lib()
+    fe = fe80 if n_mels == 80 else fe128
+    dev = torch.device("cuda:0")
+    try:
+        for amp in (1e-20, 1e-18, 1e-15, 1e-5, 1e10, 1e15):
+            lens = [48000, 31000, 7481, 160000]
+            clips = [np.asarray(c, np.float32) * np.float32(amp) for c in synth_batch(3, lens)]
+            clips.append(np.zeros(20000, np.float32))
+            imp = np.zeros(20000, np.float32)
+            imp[777] = amp
+            clips.append(imp)
+            clips.append(np.full(20000, amp, np.float32))
+            pcm, off, ln = pack_clips(clips, dev, 160000)
+            for sc in (None, 1.0 / amp):
+                scale = None if sc is None else torch.full((len(clips),), sc, dtype=torch.float32, device=dev)
+                res = []
+                for on in (0, 1):
+                    assert L.sttfe_set_whisper_uniform_kernel(on) == 0
+                    out = torch.full((len(clips), n_mels, 1000), -3.0, dtype=torch.float32, device=dev)
+                    fe.extract(pcm, off, ln, out=out, clip_scale=scale)
+                    torch.cuda.synchronize()
+                    res.append(out)
+                assert torch.equal(res[0].view(torch.int32), res[1].view(torch.int32)), (amp, sc)
+    finally:
+        L.sttfe_set_whisper_uniform_kernel(1)
+
+
 def test_uniform_kernel_handover_over_many_tiles(fe80):
     """The 12-wave kernel hands its power panel from the transform waves to the mel waves through two LDS counters (no
     barrier): 300 full-length clips = 19 k tiles per launch, repeated launches, every run length -- each result bit for
