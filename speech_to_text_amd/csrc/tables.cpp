@@ -178,8 +178,43 @@ static bool bands_match(const std::vector<float>& dense) {
         }
     return true;
 }
+// The weight pairs (W[m][k], W[m][k + 1]) * scale of every mel in the order in which the band-sparse projection's chain
+// visits them -- the MFMA form's accumulation order (mel_sparse_dot in whisper_logmel12.inc walks the same loops) -- as one
+// contiguous stream behind the A fragments: the mel waves read it with scalar loads, MelBand::woff[m] is mel m's first pair.
+template <int NM>
+static void pair_stream(const std::vector<float>& dense, float scale, std::vector<float>& out) {
+    using B = wh::MelBand<NM>;
+    for (int m = 0; m < NM; ++m) {
+        const int ks = B::kstart[m / 16], ng = B::nsteps[m / 16] / 4, lo = B::lo[m], hi = B::hi[m];
+        int n = 0;
+        for (int g = 0; g < ng; ++g) {
+            const int k0 = ks + 16 * g;
+            if (k0 + 15 < lo || k0 > hi) continue;
+            for (int h = 0; h < 2; ++h)
+                for (int kq = 0; kq < 4; ++kq) {
+                    const int k = k0 + 4 * kq + 2 * h;
+                    if (k + 1 < lo || k > hi) continue;
+                    for (int i = 0; i < 2; ++i) out.push_back(k + i < 201 ? dense[(size_t)m * 201 + k + i] * scale : 0.0f);
+                    ++n;
+                }
+        }
+        if (n != B::woff[m + 1] - B::woff[m]) {   // stale header: no stream, the kernel keeps the MFMA form
+            out.clear();
+            return;
+        }
+    }
+}
 static bool whisper_bands_match(const std::vector<float>& dense, int n_mels) {
     return n_mels == 80 ? bands_match<80>(dense) : (n_mels == 128 ? bands_match<128>(dense) : false);
+}
+template <int NM>
+static bool plan_is(const MelPlan& p) {
+    for (int mt = 0; mt < NM / 16; ++mt)
+        if (p.kstart[mt] != wh::MelBand<NM>::kstart[mt] || p.nsteps[mt] != wh::MelBand<NM>::nsteps[mt]) return false;
+    return true;
+}
+static bool plan_equals_bands(const MelPlan& p, int n_mels) {
+    return n_mels == 80 ? plan_is<80>(p) : (n_mels == 128 ? plan_is<128>(p) : false);
 }
 
 static int whisper_tables(int n_mels, std::vector<unsigned char>& blob) {
@@ -194,7 +229,13 @@ static int whisper_tables(int n_mels, std::vector<unsigned char>& blob) {
     h.magic = kWhisperMagic;
     h.n_mels = n_mels;
     h.afrag_floats = (int32_t)afrag.size();
-    h.reserved = whisper_bands_match(dense, n_mels) ? 1 : 0;   // bit 0: whisper_mel_bands.h describes this bank (band-sparse projection allowed)
+    // bit 0: whisper_mel_bands.h describes this bank and the pair stream follows the A fragments (band-sparse projection)
+    std::vector<float> stream;
+    if (whisper_bands_match(dense, n_mels) && (int)plan_equals_bands(h.plan, n_mels)) {
+        if (n_mels == 80) pair_stream<80>(dense, 0.25f, stream);
+        else pair_stream<128>(dense, 0.25f, stream);
+    }
+    h.reserved = stream.empty() ? 0 : 1;
     for (int i = 0; i < 400; ++i) h.window[i] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * i / 400.0));
     for (int k1 = 0; k1 < 20; ++k1)
         for (int j = 0; j < 20; ++j) {
@@ -202,9 +243,10 @@ static int whisper_tables(int n_mels, std::vector<unsigned char>& blob) {
             h.twiddle[2 * (20 * k1 + j)] = (float)std::cos(2.0 * M_PI * m / 400.0);
             h.twiddle[2 * (20 * k1 + j) + 1] = (float)(-std::sin(2.0 * M_PI * m / 400.0));
         }
-    blob.resize(sizeof(h) + afrag.size() * sizeof(float));
+    blob.resize(sizeof(h) + (afrag.size() + stream.size()) * sizeof(float));
     std::memcpy(blob.data(), &h, sizeof(h));
     std::memcpy(blob.data() + sizeof(h), afrag.data(), afrag.size() * sizeof(float));
+    if (!stream.empty()) std::memcpy(blob.data() + sizeof(h) + afrag.size() * sizeof(float), stream.data(), stream.size() * sizeof(float));
     return STTFE_OK;
 }
 
