@@ -229,13 +229,13 @@ static int whisper_tables(int n_mels, std::vector<unsigned char>& blob) {
     h.magic = kWhisperMagic;
     h.n_mels = n_mels;
     h.afrag_floats = (int32_t)afrag.size();
-    // bit 0: whisper_mel_bands.h describes this bank and the pair stream follows the A fragments (band-sparse projection)
+    // bits 0 + 1: whisper_mel_bands.h describes this bank and the pair stream follows the A fragments (band-sparse projection)
     std::vector<float> stream;
     if (whisper_bands_match(dense, n_mels) && (int)plan_equals_bands(h.plan, n_mels)) {
         if (n_mels == 80) pair_stream<80>(dense, 0.25f, stream);
         else pair_stream<128>(dense, 0.25f, stream);
     }
-    h.reserved = stream.empty() ? 0 : 1;
+    h.reserved = stream.empty() ? 0 : 3;   // bit 1: the stream is there (bit 0 alone: a blob of the build that read the weights from LDS)
     for (int i = 0; i < 400; ++i) h.window[i] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * i / 400.0));
     for (int k1 = 0; k1 < 20; ++k1)
         for (int j = 0; j < 20; ++j) {

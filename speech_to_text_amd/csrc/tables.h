@@ -47,11 +47,12 @@ struct WhisperTablesHeader {
     uint32_t magic;
     int32_t n_mels;
     int32_t afrag_floats;
-    int32_t reserved;
+    int32_t reserved;           // bits 0, 1: whisper_mel_bands.h describes this bank / the weight-pair stream follows the A fragments
     MelPlan plan;
     float window[400];          // periodic Hann
     float twiddle[800];         // [k1][j] complex: W_400^(j k1) = (cos, -sin)(2 pi j k1 / 400)
-    // followed by: float afrag[afrag_floats]
+    // followed by: float afrag[afrag_floats]; then, if reserved & 2, the weight pairs of every mel in the order of the
+    // band-sparse projection's chain (2 * MelBand::woff[n_mels] floats; whisper_logmel12.inc reads them with scalar loads)
 };
 
 // Polyphase windowed-sinc resampler (torchaudio.transforms.Resample defaults).  Output sample

@@ -67,17 +67,17 @@ def test_whisper_mel_bank_matches_oracle(n_mels):
 def test_generated_mel_bands_describe_the_bank():
     """csrc/whisper_mel_bands.h (tools/gen_mel_bands.py) holds the first / last non-zero bin of every mel row: the 12-wave
     kernel's band-sparse projection skips every product outside them.  The tables builder checks the header against the bank
-    it builds and says so in the blob's header (word 3, bit 0): set for the two Whisper extractors, clear for any other bin
+    it builds and says so in the blob's header (word 3, bits 0 and 1: bands verified, weight-pair stream appended): set for the two Whisper extractors, clear for any other bin
     count (those take the MFMA projection).  The header itself is what the generator would write today."""
     import struct
     L = _lib.lib()
-    for n_mels, want in ((80, 1), (128, 1), (40, 0), (64, 0)):
+    for n_mels, want in ((80, 3), (128, 3), (40, 0), (64, 0)):
         n = ctypes.c_size_t()
         _lib.check(L.sttfe_whisper_tables_bytes(n_mels, ctypes.byref(n)))
         blob = ctypes.create_string_buffer(n.value)
         _lib.check(L.sttfe_whisper_tables_build(n_mels, blob, n))
         magic, nm, afrag_floats, flags = struct.unpack("Iiii", blob.raw[:16])
-        assert nm == n_mels and (flags & 1) == want
+        assert nm == n_mels and (flags & 3) == want
     text = open(os.path.join(ROOT, "speech_to_text_amd", "csrc", "whisper_mel_bands.h")).read()
     for n_mels in (80, 128):
         dense = np.empty((n_mels, 201), dtype=np.float32)
@@ -87,6 +87,27 @@ def test_generated_mel_bands_describe_the_bank():
         assert f"lo[{n_mels}] = {{{', '.join(map(str, lo))}}};" in text
         assert f"hi[{n_mels}] = {{{', '.join(map(str, hi))}}};" in text
         assert all(int(np.count_nonzero(r)) == h - l + 1 for r, l, h in zip(dense, lo, hi))
+        # the weight-pair stream behind the A fragments: every mel's pairs (W[m][k], W[m][k + 1]) / 4 in the order of the
+        # MFMA form's two accumulation chains (bin offsets 0 4 8 12 2 6 10 14 of every 16-bin group of the mel tile's k range)
+        plan = {80: ([0, 12, 28, 56, 104], [4, 8, 8, 16, 24]), 128: ([0, 8, 16, 28, 40, 60, 88, 124], [4, 4, 4, 4, 8, 12, 12, 20])}[n_mels]
+        want = []
+        for m in range(n_mels):
+            ks, ns = plan[0][m // 16], plan[1][m // 16]
+            for g in range(ns // 4):
+                for h in range(2):
+                    for kq in range(4):
+                        k = ks + 16 * g + 4 * kq + 2 * h
+                        if ks + 16 * g + 15 < lo[m] or ks + 16 * g > hi[m] or k + 1 < lo[m] or k > hi[m]:
+                            continue
+                        want += [dense[m, k] * 0.25, dense[m, k + 1] * 0.25 if k + 1 < 201 else 0.0]
+        n = ctypes.c_size_t()
+        _lib.check(L.sttfe_whisper_tables_bytes(n_mels, ctypes.byref(n)))
+        blob = ctypes.create_string_buffer(n.value)
+        _lib.check(L.sttfe_whisper_tables_build(n_mels, blob, n))
+        afrag_floats = struct.unpack("Iiii", blob.raw[:16])[2]
+        stream = np.frombuffer(blob.raw, dtype=np.float32)[-len(want):]
+        assert n.value % 4 == 0 and len(blob.raw) // 4 - len(want) >= afrag_floats
+        assert np.array_equal(stream, np.asarray(want, dtype=np.float32))
 
 
 def test_kaldi_mel_bank_matches_oracle():
