@@ -321,6 +321,47 @@ def test_band_sparse_projection_equals_the_mfma_projection_on_amplitude_extremes
         L.sttfe_set_whisper_uniform_kernel(1)
 
 
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_mfma_form_of_the_12_wave_kernel_gives_the_same_bits(n_mels, fe80, fe128):
+    """STTFE_WH12_MFMA=1 (read once per process: a child process) makes the 12-wave kernel's mel waves project with MFMAs,
+    the form that shipped before the band-sparse one and the fall-back for tables whose bank whisper_mel_bands.h does not
+    describe: a uniform and a ragged, masked batch must give the digest of the default form."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import hashlib, numpy as np, torch
+from speech_to_text_amd.processors import HipWhisperFeatureExtractor, pack_clips
+from speech_to_text_amd.synth import synth_batch
+dev = torch.device("cuda:0")
+fe = HipWhisperFeatureExtractor(%d, device=dev)
+h = hashlib.sha256()
+rng = np.random.default_rng(12)
+for lens, k in (([480000] * 6, 0), ([480000, 16000, 250000, 1, 7481, 0, 479841] + rng.integers(1, 480001, 30).tolist(), 5)):
+    pcm, off, ln = pack_clips(list(synth_batch(7 + k, lens)), dev, 480000)
+    tbl = None
+    if k:
+        t = np.zeros((len(lens), k, 3), dtype=np.int32)
+        t[:, :, 0] = rng.integers(0, 2, size=(len(lens), k))
+        t[:, :, 1] = rng.integers(0, 70, size=(len(lens), k))
+        t[:, :, 2] = t[:, :, 1] + rng.integers(0, 40, size=(len(lens), k))
+        tbl = torch.tensor(t, device=dev)
+    out = torch.full((len(lens), %d, 3000), -3.0, dtype=torch.float32, device=dev)
+    fe.extract(pcm, off, ln, out=out, mask_table=tbl)
+    h.update(out.cpu().numpy().tobytes())
+print("digest", h.hexdigest())
+""" % (n_mels, n_mels)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for mfma in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, STTFE_WH12_MFMA=mfma),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "digest " in r.stdout, (mfma, r.stdout[-500:], r.stderr[-2000:])
+        digests.append(r.stdout.split("digest ")[1].split()[0])
+    assert digests[0] == digests[1]
+
+
 def test_uniform_kernel_handover_over_many_tiles(fe80):
     """The 12-wave kernel hands its power panel from the transform waves to the mel waves through two LDS counters (no
     barrier): 300 full-length clips = 19 k tiles per launch, repeated launches, every run length -- each result bit for
