@@ -8,6 +8,7 @@ from speech_to_text_amd import _lib
 from speech_to_text_amd.processors import HipWhisperFeatureExtractor
 from speech_to_text_amd.synth import synth_batch_device
 B = 1024
+N = int(os.environ.get("STAMP_CLIP_SAMPLES", "480000"))        # uniform clips of this length (480000 = 30 s)
 dev = torch.device("cuda:0")
 L = _lib.lib()
 assert L.sttfe_set_whisper_uniform_kernel(1) == 0      # the diagnostic builds start with it off
@@ -16,15 +17,16 @@ buf = torch.zeros(nblk * 12 * 20, dtype=torch.int64, device=dev)
 L.sttfe_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
 assert L.sttfe_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr())) == 0
 fe = HipWhisperFeatureExtractor(80, device=dev)
-pcm = synth_batch_device(1, B, 480000, dev).reshape(-1)
-off = (torch.arange(B, dtype=torch.int64) * 480000).to(dev)
-ln = torch.full((B,), 480000, dtype=torch.int32, device=dev)
+pcm = synth_batch_device(1, B, N, dev).reshape(-1)
+off = (torch.arange(B, dtype=torch.int64) * N).to(dev)
+ln = torch.full((B,), N, dtype=torch.int32, device=dev)
 out = torch.empty((B, 80, 3000), dtype=torch.float32, device=dev)
 for _ in range(3):
     fe.extract(pcm, off, ln, out=out)
 torch.cuda.synchronize()
 raw = buf.view(nblk, 12, 20).double()
-tiles = B * 63 / nblk
+tiles = B * ((N // 160 + 1 + 47) // 48) / nblk
+print(f'{B} uniform clips of {N} samples, {tiles:.1f} tiles per workgroup')
 names = ["s1: window, DFT, twiddles, slab", "wait for the panel (freed)", "panel rows + signal", "mel: wait for the panel", "mel units + keys", "loop top", "s2: DFT, partner, power", "tail"]
 for role, sl in (("transform waves 0-7", slice(0, 8)), ("mel waves 8-11", slice(8, 12))):
     r = raw[:, sl, :]
