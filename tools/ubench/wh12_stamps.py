@@ -20,13 +20,14 @@ fe = HipWhisperFeatureExtractor(80, device=dev)
 pcm = synth_batch_device(1, B, N, dev).reshape(-1)
 off = (torch.arange(B, dtype=torch.int64) * N).to(dev)
 ln = torch.full((B,), N, dtype=torch.int32, device=dev)
-out = torch.empty((B, 80, 3000), dtype=torch.float32, device=dev)
+NF = int(os.environ.get("STAMP_N_FRAMES", "3000"))            # compact output layouts: frames per row
+out = torch.empty((B, 80, NF), dtype=torch.float32, device=dev)
 for _ in range(3):
     fe.extract(pcm, off, ln, out=out)
 torch.cuda.synchronize()
 raw = buf.view(nblk, 12, 20).double()
-tiles = B * ((N // 160 + 1 + 47) // 48) / nblk
-print(f'{B} uniform clips of {N} samples, {tiles:.1f} tiles per workgroup')
+tiles = B * ((min(N // 160 + 1, NF) + 47) // 48) / nblk
+print(f'{B} uniform clips of {N} samples, {NF} frames per output row, {tiles:.1f} tiles per workgroup')
 names = ["s1: window, DFT, twiddles, slab", "wait for the panel (freed)", "panel rows + signal", "mel: wait for the panel", "mel units + keys", "loop top", "s2: DFT, partner, power", "tail"]
 for role, sl in (("transform waves 0-7", slice(0, 8)), ("mel waves 8-11", slice(8, 12))):
     r = raw[:, sl, :]
