@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Small fixed workload for rocprofv3 passes: a few launches of one front-end path.
 
-    python3 tools/prof_step.py whisper [batch] [steps] [n_mels]
+    python3 tools/prof_step.py whisper [batch] [steps] [n_mels] [samples per clip] [frames per output row]
     python3 tools/prof_step.py kaldi   [batch] [steps]
     python3 tools/prof_step.py resample [batch] [steps]
 """
@@ -21,11 +21,13 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 dev = torch.device("cuda:0")
 if what == "whisper":
     n_mels = int(sys.argv[4]) if len(sys.argv) > 4 else 80
+    n_samples = int(sys.argv[5]) if len(sys.argv) > 5 else 480000        # uniform clips of this length
+    n_frames = int(sys.argv[6]) if len(sys.argv) > 6 else 3000            # (compact output layouts: fewer frames per row)
     fe = HipWhisperFeatureExtractor(n_mels, device=dev)
-    pcm = synth_batch_device(1, batch, 480000, dev).reshape(-1)
-    off = (torch.arange(batch, dtype=torch.int64) * 480000).to(dev)
-    ln = torch.full((batch,), 480000, dtype=torch.int32, device=dev)
-    out = torch.empty((batch, n_mels, 3000), dtype=torch.float32, device=dev)
+    pcm = synth_batch_device(1, batch, n_samples, dev).reshape(-1)
+    off = (torch.arange(batch, dtype=torch.int64) * n_samples).to(dev)
+    ln = torch.full((batch,), n_samples, dtype=torch.int32, device=dev)
+    out = torch.empty((batch, n_mels, n_frames), dtype=torch.float32, device=dev)
     for _ in range(steps):
         fe.extract(pcm, off, ln, out=out)
 elif what == "kaldi":
